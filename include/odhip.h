@@ -1,0 +1,161 @@
+/*
+ * odhip.h — C ABI of libodhip.so, the MI355X (gfx950) drop-in for the hot path of
+ * ak110/object_detector (Darknet53 backbone + multi-scale prior-box head -> decode -> per-class NMS,
+ * plus prior-box assignment / loss for training).
+ *
+ * The reference has NO FFI for this path: everything below `ObjectDetector.predict`
+ * (reference voc_validate.py:27, voc_evaluate.py:27) and `od.pb.encode_truth / decode_locs`
+ * (reference check_assign.py:21,27) lives in the un-vendored `pytoolkit` submodule.
+ * The entry points here are therefore BUILD-DEFINED; each one names the reference call site whose
+ * device work it replaces.  INTEGRATION.md shows the ctypes binding a pytoolkit maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative OD_ERR_* otherwise; od_last_error() gives text
+ *   - all tensor arguments are raw DEVICE pointers + explicit dims; `stream` is a hipStream_t passed as void*
+ *   - no hidden allocation in any per-step call: the caller owns every buffer, including workspaces whose
+ *     size is returned by the matching *_workspace_bytes() query.  od_ctx owns only a 4 KiB zero page.
+ *   - kernels are asynchronous on `stream`; launch errors are mapped to return codes right after launch
+ *   - activations are NHWC; f16 storage, f32 accumulation (MFMA v_mfma_f32_16x16x32_f16)
+ */
+#ifndef ODHIP_H
+#define ODHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OD_OK 0
+#define OD_ERR_INVALID (-1)   /* bad argument / unsupported shape */
+#define OD_ERR_HIP (-2)       /* HIP runtime error (text in od_last_error) */
+#define OD_ERR_WORKSPACE (-3) /* workspace too small */
+#define OD_ERR_COMM (-4)      /* RCCL error */
+
+/* activation enum of the fused conv epilogue (backbone leaky(0.1), neck/head ELU) */
+#define OD_ACT_LINEAR 0
+#define OD_ACT_LEAKY 1
+#define OD_ACT_ELU 2
+
+#define OD_RES_NONE 0
+#define OD_RES_SAME 1 /* residual tensor has the output's shape: Darknet53 shortcut */
+#define OD_RES_UP2 2  /* residual tensor is [B,Ho/2,Wo/2,Cout], nearest-upsampled 2x: FPN top-down add */
+
+#define OD_DT_F16 0
+#define OD_DT_F32 1
+
+typedef struct od_ctx od_ctx;
+
+const char* od_last_error(void);
+int od_version(void);
+
+int od_ctx_create(int device, od_ctx** out);
+int od_ctx_destroy(od_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1/K2: fused conv2d forward.  Replaces the Keras Conv2D+BatchNormalization+activation(+Add) layers
+ * that `ObjectDetector.predict` executes (reference voc_validate.py:27; network per docs/MODEL.md:5-21).
+ * out = act(scale[c] * conv(x, w)[c] + bias[c]) (+ residual), 'same' padding (ksize/2).
+ *   x      f16 [B,H,W,Cin] NHWC, Cin % 8 == 0
+ *   w      f16 packed [Cout_pad][Kpad], k = (dy*ksize+dx)*Cin + cin, zero padded
+ *          (dims from od_conv_weight_dims; rows beyond Cout and k beyond ksize*ksize*Cin are zero)
+ *   scale, bias  f32 [Cout_pad]  (inference: BatchNorm folded; training fwd: identity/conv bias)
+ *   res    f16 residual or NULL (res_mode)
+ *   out    f16 or f32; element (b, ho, wo, c) is written at
+ *          out[b*out_batch_stride + (ho*Wo+wo)*out_pix_stride + c]  (0 strides = dense NHWC)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct od_conv_desc {
+  const void* x;
+  const void* w;
+  const float* scale;
+  const float* bias;
+  const void* res;
+  void* out;
+  int32_t B, H, W, Cin, Cout;
+  int32_t ksize;  /* 1 or 3 */
+  int32_t stride; /* 1 or 2 */
+  int32_t act;    /* OD_ACT_* */
+  float alpha;    /* leaky slope / ELU alpha */
+  int32_t res_mode;
+  int32_t out_dtype; /* OD_DT_* */
+  int64_t out_batch_stride;
+  int64_t out_pix_stride;
+  int32_t tile_cfg; /* -1 = auto; otherwise index into the tile-config table (od_conv_num_tile_cfgs) */
+} od_conv_desc;
+
+int od_conv_weight_dims(int cout, int cin, int ksize, int* cout_pad, int* kpad);
+int od_conv_num_tile_cfgs(void);
+int od_conv2d_fwd(od_ctx* ctx, const od_conv_desc* d, void* stream);
+
+/* K3: first layer, uint8 RGB image in, 3x3 stride-1 conv 3->Cout (Cout = 32), input normalisation folded
+ * into scale.  x u8 [B,H,W,3]; w f16 packed [Cout][32] (k = (dy*3+dx)*3 + c, k >= 27 zero);
+ * out f16 [B,H,W,Cout].  Replaces the image preprocess + first Conv2D of predict (voc_validate.py:27). */
+int od_conv_first_fwd(od_ctx* ctx, const uint8_t* x, const void* w, const float* scale, const float* bias,
+                      void* out, int B, int H, int W, int Cout, int act, float alpha, void* stream);
+
+/* K4 (standalone form; the planner fuses it into the lateral conv via OD_RES_UP2):
+ * out[b,y,x,c] = a[b,y,x,c] + up[b,y/2,x/2,c], all f16 NHWC.  docs/MODEL.md:7 "FPN-like" top-down path. */
+int od_upsample2x_add(od_ctx* ctx, const void* a, const void* up, void* out, int B, int H, int W, int C,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K5+K6: head post-process.  pred f32 [B,P,2+NC+4] (col 0/1 = not-object/object logits, 2..2+NC class logits,
+ * last 4 = corner-form box offsets: reference check_assign.py:25-27 layout).
+ *   conf[b,p,c]  = softmax2(pred[b,p,0:2])[1] * softmax(pred[b,p,2:2+NC])[c]      (docs/MODEL.md:54-58)
+ *   boxes[b,p,:] = clip01(priors[p] + loc * loc_scale * [pw,ph,pw,ph])              (od.pb.decode_locs)
+ * priors f32 [P,4] corner form, normalised image coordinates.
+ * ---------------------------------------------------------------------------------------------- */
+int od_head_postprocess(od_ctx* ctx, const float* pred, const float* priors, float* conf, float* boxes,
+                        int B, int P, int NC, float loc_scale, int clip, void* stream);
+
+/* K6 alone: od.pb.decode_locs(locs) (reference check_assign.py:27): zero offsets decode to the priors. */
+int od_decode_locs(od_ctx* ctx, const float* locs, const float* priors, float* boxes, int N, int P,
+                   float loc_scale, int clip, void* stream);
+
+/* K7: per image, the K candidates with the largest (conf desc, flat index asc) among conf > conf_threshold,
+ * flat index = p*NC + c.  keys u64 [B,K] = (float_bits(conf) << 32) | (0xFFFFFFFF - flat), unsorted,
+ * unused slots 0; counts i32 [B].  Exact radix select: no ties, no approximation. */
+size_t od_topk_workspace_bytes(int B, int N, int K);
+int od_topk_scores(od_ctx* ctx, const float* conf, int B, int N, int K, float conf_threshold,
+                   uint64_t* keys, int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
+
+/* K8: sort the K keys (bitonic), class-aware greedy NMS with a 64-bit wavefront suppression bitmask
+ * (docs/MODEL.md:78-82).  A candidate is suppressed by a kept higher-ranked candidate of the SAME class when
+ * inter > iou_threshold * (area_a + area_b - inter), all f32, no FMA contraction.
+ *   boxes f32 [B,P,4]; keys u64 [B,K]; counts i32 [B]
+ *   keep_flat i32 [B,max_det] (flat index p*NC+c in rank order, -1 padded); keep_count i32 [B]
+ *   strict != 0: suppression ignores the class (strict_nms kwarg, voc_validate.py:26; BUILD-DEFINED). K <= 1024. */
+size_t od_nms_workspace_bytes(int B, int K);
+int od_nms(od_ctx* ctx, const float* boxes, const uint64_t* keys, const int32_t* counts, int B, int P, int NC,
+           int K, float iou_threshold, int strict, int max_det, int32_t* keep_flat, int32_t* keep_count,
+           void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Native forward plan: the whole layer list of one network executed from C++ (one call per batch, optional
+ * hipGraph replay) so Python is not in the per-layer loop.  ops is an array of od_plan_op.
+ * ---------------------------------------------------------------------------------------------- */
+#define OD_OP_CONV 1
+#define OD_OP_CONV_FIRST 2
+
+typedef struct od_plan_op {
+  int32_t kind; /* OD_OP_* */
+  int32_t pad_;
+  od_conv_desc conv; /* OD_OP_CONV; OD_OP_CONV_FIRST uses x(u8), w, scale, bias, out, B,H,W,Cout,act,alpha */
+} od_plan_op;
+
+typedef struct od_plan od_plan;
+int od_plan_create(od_ctx* ctx, const od_plan_op* ops, int n_ops, od_plan** out);
+int od_plan_run(od_plan* plan, void* stream);   /* eager launches */
+int od_plan_capture(od_plan* plan, void* stream); /* capture into a hipGraph (stream must be capturable) */
+int od_plan_replay(od_plan* plan, void* stream);
+int od_plan_destroy(od_plan* plan);
+/* per-op timing for bench.py: runs the plan once with hipEvents around every op; ms[n_ops] */
+int od_plan_time_ops(od_plan* plan, void* stream, float* ms, int n_ops);
+/* name of the device kernel an op launches (for matching rocprofv3 rows) */
+const char* od_plan_op_kernel_name(od_plan* plan, int op_index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODHIP_H */

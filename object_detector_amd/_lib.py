@@ -1,0 +1,109 @@
+"""ctypes binding of libodhip.so (include/odhip.h).  There is NO fallback: a missing library is a hard error.
+
+This is the binding a pytoolkit maintainer would add for the path below `ObjectDetector.predict`
+(reference voc_validate.py:27) -- see INTEGRATION.md.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import pathlib
+
+_HERE = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libodhip.so"
+
+OD_ACT_LINEAR, OD_ACT_LEAKY, OD_ACT_ELU = 0, 1, 2
+OD_RES_NONE, OD_RES_SAME, OD_RES_UP2 = 0, 1, 2
+OD_DT_F16, OD_DT_F32 = 0, 1
+OD_OP_CONV, OD_OP_CONV_FIRST = 1, 2
+
+ACT_ENUM = {None: OD_ACT_LINEAR, "linear": OD_ACT_LINEAR, "leaky": OD_ACT_LEAKY, "elu": OD_ACT_ELU}
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p),
+        ("res", C.c_void_p), ("out", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+        ("ksize", C.c_int32), ("stride", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float),
+        ("res_mode", C.c_int32), ("out_dtype", C.c_int32),
+        ("out_batch_stride", C.c_int64), ("out_pix_stride", C.c_int64),
+        ("tile_cfg", C.c_int32),
+    ]
+
+
+class PlanOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("pad_", C.c_int32), ("conv", ConvDesc)]
+
+
+class OdError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_PROTOS = {
+    # name: (restype, argtypes)
+    "od_last_error": (C.c_char_p, []),
+    "od_version": (C.c_int, []),
+    "od_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "od_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "od_conv_weight_dims": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "od_conv_num_tile_cfgs": (C.c_int, []),
+    "od_conv2d_fwd": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_void_p]),
+    "od_conv_first_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "od_upsample2x_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_void_p]),
+    "od_head_postprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "od_decode_locs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                 C.c_int, C.c_void_p]),
+    "od_topk_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "od_topk_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "od_nms_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "od_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                         C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "od_plan_create": (C.c_int, [C.c_void_p, C.POINTER(PlanOp), C.c_int, C.POINTER(C.c_void_p)]),
+    "od_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "od_plan_capture": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "od_plan_replay": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "od_plan_destroy": (C.c_int, [C.c_void_p]),
+    "od_plan_time_ops": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int]),
+    "od_plan_op_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+
+def load(path: os.PathLike | None = None):
+    """dlopen libodhip.so and declare every prototype.  Raises OdError when the library is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = pathlib.Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise OdError(
+            f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C object_detector_amd/csrc`). There is no CPU fallback for this path.")
+    lib = C.CDLL(str(p))
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().od_last_error()
+        raise OdError(f"{what or 'libodhip'} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def conv_weight_dims(cout: int, cin: int, ksize: int):
+    a, b = C.c_int(), C.c_int()
+    check(load().od_conv_weight_dims(cout, cin, ksize, C.byref(a), C.byref(b)), "od_conv_weight_dims")
+    return a.value, b.value

@@ -1,0 +1,172 @@
+// Context, error reporting and the native forward plan of libodhip.so.
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_err[1024] = "";
+
+void od_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* od_last_error(void) { return g_err; }
+extern "C" int od_version(void) { return 100; }
+
+extern "C" int od_ctx_create(int device, od_ctx** out) {
+  OD_REQUIRE(out, "od_ctx_create: null out");
+  OD_CHECK_HIP(hipSetDevice(device));
+  od_ctx* c = new od_ctx();
+  c->device = device;
+  c->zero_page = nullptr;
+  hipDeviceProp_t prop;
+  OD_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+  c->num_cu = prop.multiProcessorCount;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    od_set_error("od_ctx_create: device %d is %s; libodhip.so is built for gfx950 (MI355X) only", device,
+                 prop.gcnArchName);
+    delete c;
+    return OD_ERR_INVALID;
+  }
+  OD_CHECK_HIP(hipMalloc(&c->zero_page, 4096));
+  OD_CHECK_HIP(hipMemset(c->zero_page, 0, 4096));
+  *out = c;
+  return OD_OK;
+}
+
+extern "C" int od_ctx_destroy(od_ctx* ctx) {
+  if (!ctx) return OD_OK;
+  if (ctx->zero_page) (void)hipFree(ctx->zero_page);
+  delete ctx;
+  return OD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward plan: the layer list of one network, launched from C++ (eager or as a replayed hipGraph).
+// ---------------------------------------------------------------------------------------------------------------
+struct od_plan {
+  od_ctx* ctx;
+  std::vector<od_plan_op> ops;
+  std::vector<const char*> names;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+static int run_op(od_plan* pl, int i, hipStream_t s) {
+  const od_plan_op& op = pl->ops[i];
+  if (op.kind == OD_OP_CONV) return od_conv2d_fwd_impl(pl->ctx, &op.conv, s, nullptr, false);
+  if (op.kind == OD_OP_CONV_FIRST) {
+    const od_conv_desc& c = op.conv;
+    return od_conv_first_fwd(pl->ctx, (const uint8_t*)c.x, c.w, c.scale, c.bias, c.out, c.B, c.H, c.W, c.Cout, c.act,
+                             c.alpha, s);
+  }
+  od_set_error("od_plan: unknown op kind %d at %d", op.kind, i);
+  return OD_ERR_INVALID;
+}
+
+extern "C" int od_plan_create(od_ctx* ctx, const od_plan_op* ops, int n_ops, od_plan** out) {
+  OD_REQUIRE(ctx && ops && n_ops > 0 && out, "od_plan_create: bad args");
+  od_plan* pl = new od_plan();
+  pl->ctx = ctx;
+  pl->ops.assign(ops, ops + n_ops);
+  pl->names.resize(n_ops, "");
+  for (int i = 0; i < n_ops; ++i) {
+    if (ops[i].kind == OD_OP_CONV) {
+      const char* nm = nullptr;
+      int rc = od_conv2d_fwd_impl(ctx, &ops[i].conv, nullptr, &nm, true);  // validates the descriptor
+      if (rc != OD_OK) {
+        delete pl;
+        return rc;
+      }
+      pl->names[i] = nm;
+    } else if (ops[i].kind == OD_OP_CONV_FIRST) {
+      pl->names[i] = od_conv_first_kernel_name();
+    } else {
+      od_set_error("od_plan_create: unknown op kind %d at %d", ops[i].kind, i);
+      delete pl;
+      return OD_ERR_INVALID;
+    }
+  }
+  *out = pl;
+  return OD_OK;
+}
+
+extern "C" int od_plan_run(od_plan* pl, void* stream) {
+  OD_REQUIRE(pl, "od_plan_run: null plan");
+  for (size_t i = 0; i < pl->ops.size(); ++i) {
+    int rc = run_op(pl, (int)i, (hipStream_t)stream);
+    if (rc != OD_OK) return rc;
+  }
+  return OD_OK;
+}
+
+extern "C" int od_plan_capture(od_plan* pl, void* stream) {
+  OD_REQUIRE(pl, "od_plan_capture: null plan");
+  hipStream_t s = (hipStream_t)stream;
+  OD_REQUIRE(s != nullptr, "od_plan_capture: needs a non-default stream");
+  // warm every kernel once outside capture (function attributes are set lazily on first launch)
+  int rc = od_plan_run(pl, stream);
+  if (rc != OD_OK) return rc;
+  OD_CHECK_HIP(hipStreamSynchronize(s));
+  if (pl->exec) {
+    (void)hipGraphExecDestroy(pl->exec);
+    pl->exec = nullptr;
+  }
+  if (pl->graph) {
+    (void)hipGraphDestroy(pl->graph);
+    pl->graph = nullptr;
+  }
+  OD_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  rc = od_plan_run(pl, stream);
+  hipError_t e = hipStreamEndCapture(s, &pl->graph);
+  if (rc != OD_OK) return rc;
+  if (e != hipSuccess) {
+    od_set_error("od_plan_capture: hipStreamEndCapture -> %s", hipGetErrorString(e));
+    return OD_ERR_HIP;
+  }
+  OD_CHECK_HIP(hipGraphInstantiate(&pl->exec, pl->graph, nullptr, nullptr, 0));
+  return OD_OK;
+}
+
+extern "C" int od_plan_replay(od_plan* pl, void* stream) {
+  OD_REQUIRE(pl && pl->exec, "od_plan_replay: plan not captured");
+  OD_CHECK_HIP(hipGraphLaunch(pl->exec, (hipStream_t)stream));
+  return OD_OK;
+}
+
+extern "C" int od_plan_destroy(od_plan* pl) {
+  if (!pl) return OD_OK;
+  if (pl->exec) (void)hipGraphExecDestroy(pl->exec);
+  if (pl->graph) (void)hipGraphDestroy(pl->graph);
+  delete pl;
+  return OD_OK;
+}
+
+extern "C" int od_plan_time_ops(od_plan* pl, void* stream, float* ms, int n_ops) {
+  OD_REQUIRE(pl && ms && n_ops == (int)pl->ops.size(), "od_plan_time_ops: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<hipEvent_t> ev(n_ops + 1);
+  for (auto& e : ev) OD_CHECK_HIP(hipEventCreate(&e));
+  OD_CHECK_HIP(hipEventRecord(ev[0], s));
+  int rc = OD_OK;
+  for (int i = 0; i < n_ops && rc == OD_OK; ++i) {
+    rc = run_op(pl, i, s);
+    if (rc == OD_OK) OD_CHECK_HIP(hipEventRecord(ev[i + 1], s));
+  }
+  if (rc == OD_OK) {
+    OD_CHECK_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < n_ops; ++i) OD_CHECK_HIP(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
+
+extern "C" const char* od_plan_op_kernel_name(od_plan* pl, int i) {
+  if (!pl || i < 0 || i >= (int)pl->names.size()) return "";
+  return pl->names[i];
+}

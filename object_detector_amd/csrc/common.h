@@ -1,0 +1,55 @@
+// Internal helpers shared by every translation unit of libodhip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/odhip.h"
+
+struct od_ctx {
+  int device;
+  void* zero_page;  // 4 KiB of zeros: source for padded / out-of-range lanes of LDS-DMA gathers
+  int num_cu;
+};
+
+void od_set_error(const char* fmt, ...);
+
+#define OD_CHECK_HIP(expr)                                                                   \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      od_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_));     \
+      return OD_ERR_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+#define OD_CHECK_LAUNCH()                                                                    \
+  do {                                                                                       \
+    hipError_t e_ = hipGetLastError();                                                       \
+    if (e_ != hipSuccess) {                                                                  \
+      od_set_error("%s:%d: kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return OD_ERR_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+#define OD_REQUIRE(cond, ...)   \
+  do {                          \
+    if (!(cond)) {              \
+      od_set_error(__VA_ARGS__); \
+      return OD_ERR_INVALID;    \
+    }                           \
+  } while (0)
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int od_ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int od_round_up(int a, int b) { return od_ceil_div(a, b) * b; }
+
+// conv launcher (conv_mfma.hip); kernel_name receives the device symbol launched (may be NULL)
+int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, const char** kernel_name,
+                       bool dry_run);
+const char* od_conv_first_kernel_name();

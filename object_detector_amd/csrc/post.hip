@@ -1,0 +1,154 @@
+// K4 (standalone), K5, K6: FPN top-down add, head post-process (objectness x class confidence) and prior-box decode.
+// All HBM-bound elementwise work; rows are staged through LDS so that every global access is a full-line access.
+// Compiled with -ffp-contract=off: the decode arithmetic is the bit-exact f32 sequence of oracle/postprocess.py.
+#include "common.h"
+
+namespace {
+
+// boxes = prior + (loc * loc_scale) * [pw, ph, pw, ph], optional clip to [0,1]   (od.pb.decode_locs,
+// reference check_assign.py:27: zero offsets decode to the prior itself)
+__device__ __forceinline__ f32x4 decode_one(f32x4 loc, f32x4 pr, float loc_scale, int clip) {
+  const float pw = pr[2] - pr[0], ph = pr[3] - pr[1];
+  f32x4 o;
+  o[0] = pr[0] + (loc[0] * loc_scale) * pw;
+  o[1] = pr[1] + (loc[1] * loc_scale) * ph;
+  o[2] = pr[2] + (loc[2] * loc_scale) * pw;
+  o[3] = pr[3] + (loc[3] * loc_scale) * ph;
+  if (clip) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fminf(fmaxf(o[e], 0.f), 1.f);
+  }
+  return o;
+}
+
+constexpr int PP_ROWS = 256;  // priors per workgroup
+
+// pred [B*P, C] -> conf [B*P, NC], boxes [B*P, 4];  C = 2 + NC + 4
+__global__ __launch_bounds__(256) void od_head_post(const float* __restrict__ pred, const float* __restrict__ priors,
+                                                    float* __restrict__ conf, float* __restrict__ boxes,
+                                                    long long rows, int P, int NC, float loc_scale, int clip) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int C = NC + 6;
+  const int tid = threadIdx.x;
+  const long long r0 = (long long)blockIdx.x * PP_ROWS;
+  const int nrows = (int)((rows - r0) < PP_ROWS ? (rows - r0) : PP_ROWS);
+  float* sin = sm;                  // [PP_ROWS][C]
+  float* sout = sm + PP_ROWS * C;   // [PP_ROWS][NC]
+  // coalesced load (r0*C*4 bytes is 16-B aligned because PP_ROWS*C*4 is)
+  const int nvec = nrows * C;
+  const float* src = pred + r0 * C;
+  for (int i = tid * 4; i < nvec; i += 256 * 4) {
+    if (i + 3 < nvec) {
+      *(f32x4*)(sin + i) = *(const f32x4*)(src + i);
+    } else {
+      for (int e = i; e < nvec; ++e) sin[e] = src[e];
+    }
+  }
+  __syncthreads();
+  if (tid < nrows) {
+    const float* row = sin + tid * C;
+    const float obj = 1.f / (1.f + expf(row[0] - row[1]));
+    float mx = row[2];
+    for (int c = 1; c < NC; ++c) mx = fmaxf(mx, row[2 + c]);
+    float s = 0.f;
+    float* orow = sout + tid * NC;
+    for (int c = 0; c < NC; ++c) {
+      const float e = expf(row[2 + c] - mx);
+      orow[c] = e;
+      s += e;
+    }
+    for (int c = 0; c < NC; ++c) orow[c] = obj * (orow[c] / s);
+    const long long r = r0 + tid;
+    const int p = (int)(r % P);
+    const f32x4 loc = {row[2 + NC], row[3 + NC], row[4 + NC], row[5 + NC]};
+    const f32x4 pr = *(const f32x4*)(priors + (long long)p * 4);
+    *(f32x4*)(boxes + r * 4) = decode_one(loc, pr, loc_scale, clip);
+  }
+  __syncthreads();
+  const int nout = nrows * NC;
+  float* dst = conf + r0 * NC;
+  for (int i = tid * 4; i < nout; i += 256 * 4) {
+    if (i + 3 < nout) {
+      *(f32x4*)(dst + i) = *(const f32x4*)(sout + i);
+    } else {
+      for (int e = i; e < nout; ++e) dst[e] = sout[e];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void od_decode(const float* __restrict__ locs, const float* __restrict__ priors,
+                                                 float* __restrict__ boxes, long long rows, int P, float loc_scale,
+                                                 int clip) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const int p = (int)(r % P);
+  const f32x4 loc = *(const f32x4*)(locs + r * 4);
+  const f32x4 pr = *(const f32x4*)(priors + (long long)p * 4);
+  *(f32x4*)(boxes + r * 4) = decode_one(loc, pr, loc_scale, clip);
+}
+
+// out[b,y,x,c] = a[b,y,x,c] + up[b,y/2,x/2,c]; 8 channels (16 B) per thread
+__global__ __launch_bounds__(256) void od_up2_add(const f16* __restrict__ a, const f16* __restrict__ up,
+                                                  f16* __restrict__ out, long long nvec, int H, int W, int C8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C8);
+    long long pix = i / C8;
+    const int x = (int)(pix % W);
+    pix /= W;
+    const int y = (int)(pix % H);
+    const long long b = pix / H;
+    const long long ui = ((b * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * C8 + c;
+    const f16x8 va = *(const f16x8*)(a + i * 8);
+    const f16x8 vu = *(const f16x8*)(up + ui * 8);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)((float)va[e] + (float)vu[e]);
+    *(f16x8*)(out + i * 8) = o;
+  }
+}
+
+}  // namespace
+
+extern "C" int od_head_postprocess(od_ctx* ctx, const float* pred, const float* priors, float* conf, float* boxes,
+                                   int B, int P, int NC, float loc_scale, int clip, void* stream) {
+  OD_REQUIRE(ctx && pred && priors && conf && boxes, "od_head_postprocess: null argument");
+  OD_REQUIRE(B > 0 && P > 0 && NC > 0 && NC <= 90, "od_head_postprocess: bad dims (NC <= 90)");
+  const long long rows = (long long)B * P;
+  const size_t lds = (size_t)PP_ROWS * (NC + 6 + NC) * sizeof(float);
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    OD_CHECK_HIP(hipFuncSetAttribute((const void*)&od_head_post, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_lds = lds;
+  }
+  const unsigned grid = (unsigned)((rows + PP_ROWS - 1) / PP_ROWS);
+  hipLaunchKernelGGL(od_head_post, dim3(grid), dim3(256), lds, (hipStream_t)stream, pred, priors, conf, boxes, rows, P,
+                     NC, loc_scale, clip);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
+extern "C" int od_decode_locs(od_ctx* ctx, const float* locs, const float* priors, float* boxes, int N, int P,
+                              float loc_scale, int clip, void* stream) {
+  OD_REQUIRE(ctx && locs && priors && boxes, "od_decode_locs: null argument");
+  OD_REQUIRE(N > 0 && P > 0, "od_decode_locs: bad dims");
+  const long long rows = (long long)N * P;
+  const unsigned grid = (unsigned)((rows + 255) / 256);
+  hipLaunchKernelGGL(od_decode, dim3(grid), dim3(256), 0, (hipStream_t)stream, locs, priors, boxes, rows, P, loc_scale,
+                     clip);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
+extern "C" int od_upsample2x_add(od_ctx* ctx, const void* a, const void* up, void* out, int B, int H, int W, int C,
+                                 void* stream) {
+  OD_REQUIRE(ctx && a && up && out, "od_upsample2x_add: null argument");
+  OD_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0,
+             "od_upsample2x_add: H,W must be even and C a multiple of 8");
+  const long long nvec = (long long)B * H * W * (C / 8);
+  long long blocks = (nvec + 255) / 256;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(od_up2_add, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)a,
+                     (const f16*)up, (f16*)out, nvec, H, W, C / 8);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}

@@ -1,0 +1,230 @@
+"""Device-side network: packs parameters for the HIP kernels, owns the activation buffers (torch tensors are only
+containers of HBM) and builds the native forward plan executed by libodhip.so.
+
+Replaces the Keras model graph that reference `ObjectDetector.load_voc(...)` builds and `predict` runs
+(voc_validate.py:25-27): Darknet53 conv/BN/LeakyReLU stack, FPN-like neck, shared prediction module
+(docs/MODEL.md:5-27).  HBM layout: activations NHWC f16, one buffer per layer output; the prediction convs of the
+three levels write f32 straight into their slice of pred[B, P, 2+NC+4] (level-major, then y, x, prior).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, weights as W
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Context:
+    """od_ctx wrapper (one per process / device)."""
+
+    _by_device = {}
+
+    def __init__(self, device_index: int):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self.lib.od_ctx_create(device_index, C.byref(h)), "od_ctx_create")
+        self.handle = h
+        self.device_index = device_index
+
+    @classmethod
+    def get(cls, device) -> "Context":
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise _lib.OdError(f"object_detector_amd runs on MI355X only (got device {dev}); there is no CPU path")
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        if idx not in cls._by_device:
+            cls._by_device[idx] = cls(idx)
+        return cls._by_device[idx]
+
+
+def pack_conv_weight(w_ohwi: np.ndarray):
+    """[Cout,k,k,Cin] -> f16 [Cout_pad, Kpad], k index = (dy*k+dx)*Cin + cin (the implicit-GEMM K order)."""
+    cout, k, _, cin = w_ohwi.shape
+    cout_pad, kpad = _lib.conv_weight_dims(cout, cin, k)
+    out = np.zeros((cout_pad, kpad), np.float16)
+    out[:cout, :k * k * cin] = w_ohwi.reshape(cout, k * k * cin).astype(np.float16)
+    return out
+
+
+def pack_first_weight(w_ohwi: np.ndarray):
+    cout = w_ohwi.shape[0]
+    out = np.zeros((cout, 32), np.float16)
+    out[:, :27] = w_ohwi.reshape(cout, 27).astype(np.float16)
+    return out
+
+
+def pad_vec(v: np.ndarray, n: int):
+    out = np.zeros(n, np.float32)
+    out[:len(v)] = v
+    return out
+
+
+class Net:
+    def __init__(self, params, batch_size, input_size=(320, 320), device="cuda:0", backbone_act=("leaky", 0.1),
+                 head_act=("elu", 1.0), tile_cfg=None):
+        self.ctx = Context.get(device)
+        self.lib = self.ctx.lib
+        self.device = torch.device(device)
+        self.B = int(batch_size)
+        self.H, self.W = int(input_size[0]), int(input_size[1])
+        if self.H % 32 or self.W % 32:
+            raise ValueError("input_size must be a multiple of 32 (three maps at stride 8/16/32)")
+        self.num_classes, self.neck_ch, self.tower = W.infer_arch(params)
+        self.C = 2 + self.num_classes + 4
+        self.level_hw = [(self.H // s, self.W // s) for s in (8, 16, 32)]
+        self.P = sum(h * w for h, w in self.level_hw) * W.NUM_PRIORS
+        self.tile_cfg = tile_cfg or {}
+        self._keep = []  # device tensors referenced by raw pointers in the plan
+        self._dev = {}
+        for name, cin, cout, k, _s, _bn in W.layer_specs(self.num_classes, self.neck_ch, self.tower):
+            w = params[name + ".w"]
+            assert w.shape == (cout, k, k, cin), (name, w.shape)
+            scale, bias = W.fold_bn(params, name)
+            if name == "b.conv0":
+                wp = pack_first_weight(w)
+                scale = (scale / np.float32(255.0)).astype(np.float32)  # uint8 input normalisation folded in
+                npad = cout
+            else:
+                wp = pack_conv_weight(w)
+                npad = wp.shape[0]
+            self._dev[name] = (self._to_dev(wp), self._to_dev(pad_vec(scale, npad)), self._to_dev(pad_vec(bias, npad)))
+        self.input = torch.zeros((self.B, self.H, self.W, 3), dtype=torch.uint8, device=self.device)
+        self.pred = torch.zeros((self.B, self.P, self.C), dtype=torch.float32, device=self.device)
+        self.ops = []       # (_lib.PlanOp)
+        self.op_info = []   # dict(name, flops, bytes)
+        self._build(backbone_act, head_act)
+        arr = (_lib.PlanOp * len(self.ops))(*self.ops)
+        h = C.c_void_p()
+        _lib.check(self.lib.od_plan_create(self.ctx.handle, arr, len(self.ops), C.byref(h)), "od_plan_create")
+        self.plan = h
+        self._captured = False
+
+    # ------------------------------------------------------------------------------------------------
+    def _to_dev(self, a: np.ndarray):
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        self._keep.append(t)
+        return t
+
+    def _buf(self, h, w, c):
+        t = torch.empty((self.B, h, w, c), dtype=torch.float16, device=self.device)
+        self._keep.append(t)
+        return t
+
+    def _conv(self, name, x, h, w, cin, cout, k, stride, act, res=None, res_mode=_lib.OD_RES_NONE, out=None,
+              out_f32=False, obs=0, ops=0):
+        wt, sc, bi = self._dev[name]
+        ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
+        if out is None:
+            out = self._buf(ho, wo, cout)
+        d = _lib.ConvDesc()
+        d.x, d.w, d.scale, d.bias = x.data_ptr(), wt.data_ptr(), sc.data_ptr(), bi.data_ptr()
+        d.res = res.data_ptr() if res is not None else None
+        d.out = out if isinstance(out, int) else out.data_ptr()
+        d.B, d.H, d.W, d.Cin, d.Cout = self.B, h, w, cin, cout
+        d.ksize, d.stride = k, stride
+        d.act, d.alpha = _lib.ACT_ENUM[act[0] if act else None], float(act[1]) if act else 0.0
+        d.res_mode = res_mode
+        d.out_dtype = _lib.OD_DT_F32 if out_f32 else _lib.OD_DT_F16
+        d.out_batch_stride, d.out_pix_stride = obs, ops
+        d.tile_cfg = self.tile_cfg.get(name, -1)
+        op = _lib.PlanOp()
+        op.kind = _lib.OD_OP_CONV
+        op.conv = d
+        self.ops.append(op)
+        m = self.B * ho * wo
+        osz = 4 if out_f32 else 2
+        self.op_info.append(dict(name=name, flops=2.0 * m * cout * k * k * cin,
+                                 bytes=float(self.B * h * w * cin * 2 + m * cout * osz + cout * k * k * cin * 2
+                                             + (m * cout * 2 if res_mode == _lib.OD_RES_SAME else 0)
+                                             + (m * cout // 2 if res_mode == _lib.OD_RES_UP2 else 0)),
+                                 shape=(m, cout, k * k * cin)))
+        return out, ho, wo
+
+    def _build(self, bact, hact):
+        B, H, Wd = self.B, self.H, self.W
+        # first layer (uint8 in)
+        wt, sc, bi = self._dev["b.conv0"]
+        x = self._buf(H, Wd, 32)
+        d = _lib.ConvDesc()
+        d.x, d.w, d.scale, d.bias, d.out = self.input.data_ptr(), wt.data_ptr(), sc.data_ptr(), bi.data_ptr(), x.data_ptr()
+        d.B, d.H, d.W, d.Cin, d.Cout = B, H, Wd, 3, 32
+        d.ksize, d.stride = 3, 1
+        d.act, d.alpha = _lib.ACT_ENUM[bact[0]], float(bact[1])
+        op = _lib.PlanOp()
+        op.kind = _lib.OD_OP_CONV_FIRST
+        op.conv = d
+        self.ops.append(op)
+        self.op_info.append(dict(name="b.conv0", flops=2.0 * B * H * Wd * 32 * 27,
+                                 bytes=float(B * H * Wd * (3 + 64)), shape=(B * H * Wd, 32, 27)))
+        h, w, cin = H, Wd, 32
+        taps = []
+        for si, (n, ch) in enumerate(W.STAGES, start=1):
+            x, h, w = self._conv(f"b.down{si}", x, h, w, cin, ch, 3, 2, bact)
+            for r in range(n):
+                t, _, _ = self._conv(f"b.s{si}.{r}.a", x, h, w, ch, ch // 2, 1, 1, bact)
+                x, _, _ = self._conv(f"b.s{si}.{r}.b", t, h, w, ch // 2, ch, 3, 1, bact, res=x,
+                                     res_mode=_lib.OD_RES_SAME)
+            cin = ch
+            taps.append((x, h, w, ch))
+        (c3, h3, w3, ch3), (c4, h4, w4, ch4), (c5, h5, w5, ch5) = taps[2], taps[3], taps[4]
+        nc = self.neck_ch
+        p5, _, _ = self._conv("n.lat5", c5, h5, w5, ch5, nc, 1, 1, hact)
+        m4, _, _ = self._conv("n.lat4", c4, h4, w4, ch4, nc, 1, 1, hact, res=p5, res_mode=_lib.OD_RES_UP2)
+        p4, _, _ = self._conv("n.out4", m4, h4, w4, nc, nc, 3, 1, hact)
+        m3, _, _ = self._conv("n.lat3", c3, h3, w3, ch3, nc, 1, 1, hact, res=p4, res_mode=_lib.OD_RES_UP2)
+        p3, _, _ = self._conv("n.out3", m3, h3, w3, nc, nc, 3, 1, hact)
+        self.levels = [(p3, h3, w3), (p4, h4, w4), (p5, h5, w5)]
+        self.taps = [c3, c4, c5]
+        # shared prediction module; the last conv writes f32 logits into pred[:, off:off+h*w*8, :]
+        off = 0
+        cout = W.NUM_PRIORS * self.C
+        for (x, h, w) in self.levels:
+            t = x
+            for i in range(self.tower):
+                t, _, _ = self._conv(f"h.t{i}", t, h, w, nc, nc, 3, 1, hact)
+            out_ptr = self.pred.data_ptr() + off * self.C * 4
+            self._conv("h.out", t, h, w, nc, cout, 3, 1, None, out=out_ptr, out_f32=True,
+                       obs=self.P * self.C, ops=cout)
+            off += h * w * W.NUM_PRIORS
+        assert off == self.P
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, x_u8: torch.Tensor | None = None, graph: bool = False) -> torch.Tensor:
+        """uint8 [B,H,W,3] device tensor (or None = reuse self.input) -> pred f32 [B,P,2+NC+4] (owned by the Net)."""
+        if x_u8 is not None:
+            if x_u8.shape != self.input.shape or x_u8.dtype != torch.uint8:
+                raise ValueError(f"expected uint8 {tuple(self.input.shape)}, got {x_u8.dtype} {tuple(x_u8.shape)}")
+            self.input.copy_(x_u8, non_blocking=True)
+        if graph:
+            if not self._captured:
+                s = torch.cuda.Stream(device=self.device)
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    _lib.check(self.lib.od_plan_capture(self.plan, C.c_void_p(s.cuda_stream)), "od_plan_capture")
+                torch.cuda.current_stream().wait_stream(s)
+                self._captured = True
+            _lib.check(self.lib.od_plan_replay(self.plan, _stream_ptr()), "od_plan_replay")
+        else:
+            _lib.check(self.lib.od_plan_run(self.plan, _stream_ptr()), "od_plan_run")
+        return self.pred
+
+    def time_ops(self):
+        """Per-op device time (ms) via hipEvents on the launch stream + kernel names: for bench.py's roofline."""
+        n = len(self.ops)
+        ms = (C.c_float * n)()
+        _lib.check(self.lib.od_plan_time_ops(self.plan, _stream_ptr(), ms, n), "od_plan_time_ops")
+        names = [self.lib.od_plan_op_kernel_name(self.plan, i).decode() for i in range(n)]
+        return list(ms), names
+
+    def __del__(self):
+        try:
+            if getattr(self, "plan", None):
+                self.lib.od_plan_destroy(self.plan)
+        except Exception:
+            pass

@@ -1,0 +1,84 @@
+"""Thin per-op wrappers over the C ABI (torch tensors in / out as HBM containers).  Used by the parity tests and
+by anything that wants a single kernel rather than the whole plan.  No op here has a CPU implementation."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .net import Context, _stream_ptr, pack_conv_weight, pack_first_weight, pad_vec
+
+
+def _ctx(t: torch.Tensor) -> Context:
+    if not t.is_cuda:
+        raise _lib.OdError("object_detector_amd ops need device tensors (MI355X); there is no CPU path")
+    return Context.get(t.device)
+
+
+def conv2d(x: torch.Tensor, w_ohwi: np.ndarray, scale: np.ndarray, bias: np.ndarray, stride=1, act=None, alpha=0.0,
+           res: torch.Tensor | None = None, res_mode="none", out_f32=False, tile_cfg=-1, out=None,
+           out_batch_stride=0, out_pix_stride=0):
+    """x f16 [B,H,W,Cin] (device) ; w [Cout,k,k,Cin] host array -> out f16/f32 [B,Ho,Wo,Cout]."""
+    ctx = _ctx(x)
+    assert x.dtype == torch.float16 and x.is_contiguous()
+    B, H, Wd, Cin = x.shape
+    Cout, k = w_ohwi.shape[0], w_ohwi.shape[1]
+    wp = torch.from_numpy(pack_conv_weight(w_ohwi)).to(x.device)
+    npad = wp.shape[0]
+    sc = torch.from_numpy(pad_vec(np.asarray(scale, np.float32), npad)).to(x.device)
+    bi = torch.from_numpy(pad_vec(np.asarray(bias, np.float32), npad)).to(x.device)
+    Ho, Wo = (H + stride - 1) // stride, (Wd + stride - 1) // stride
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32 if out_f32 else torch.float16, device=x.device)
+    d = _lib.ConvDesc()
+    d.x, d.w, d.scale, d.bias, d.out = x.data_ptr(), wp.data_ptr(), sc.data_ptr(), bi.data_ptr(), out.data_ptr()
+    d.res = res.data_ptr() if res is not None else None
+    d.B, d.H, d.W, d.Cin, d.Cout = B, H, Wd, Cin, Cout
+    d.ksize, d.stride = k, stride
+    d.act, d.alpha = _lib.ACT_ENUM[act], float(alpha)
+    d.res_mode = {"none": _lib.OD_RES_NONE, "same": _lib.OD_RES_SAME, "up2": _lib.OD_RES_UP2}[res_mode]
+    d.out_dtype = _lib.OD_DT_F32 if out_f32 else _lib.OD_DT_F16
+    d.out_batch_stride, d.out_pix_stride = out_batch_stride, out_pix_stride
+    d.tile_cfg = tile_cfg
+    _lib.check(ctx.lib.od_conv2d_fwd(ctx.handle, C.byref(d), _stream_ptr()), "od_conv2d_fwd")
+    return out
+
+
+def conv_first(x_u8: torch.Tensor, w_ohwi: np.ndarray, scale, bias, act="leaky", alpha=0.1):
+    ctx = _ctx(x_u8)
+    assert x_u8.dtype == torch.uint8 and x_u8.is_contiguous()
+    B, H, Wd, _ = x_u8.shape
+    Cout = w_ohwi.shape[0]
+    wp = torch.from_numpy(pack_first_weight(w_ohwi)).to(x_u8.device)
+    sc = torch.from_numpy(np.asarray(scale, np.float32)).to(x_u8.device)
+    bi = torch.from_numpy(np.asarray(bias, np.float32)).to(x_u8.device)
+    out = torch.empty((B, H, Wd, Cout), dtype=torch.float16, device=x_u8.device)
+    _lib.check(ctx.lib.od_conv_first_fwd(ctx.handle, x_u8.data_ptr(), wp.data_ptr(), sc.data_ptr(), bi.data_ptr(),
+                                         out.data_ptr(), B, H, Wd, Cout, _lib.ACT_ENUM[act], float(alpha),
+                                         _stream_ptr()), "od_conv_first_fwd")
+    return out
+
+
+def upsample2x_add(a: torch.Tensor, up: torch.Tensor):
+    ctx = _ctx(a)
+    B, H, Wd, Cc = a.shape
+    assert tuple(up.shape) == (B, H // 2, Wd // 2, Cc)
+    out = torch.empty_like(a)
+    _lib.check(ctx.lib.od_upsample2x_add(ctx.handle, a.data_ptr(), up.data_ptr(), out.data_ptr(), B, H, Wd, Cc,
+                                         _stream_ptr()), "od_upsample2x_add")
+    return out
+
+
+def decode_locs(locs: torch.Tensor, priors: torch.Tensor, loc_scale=0.1, clip=False):
+    """locs f32 [N,P,4] or [P,4] -> boxes, device-side od.pb.decode_locs (reference check_assign.py:27)."""
+    ctx = _ctx(locs)
+    squeeze = locs.dim() == 2
+    l3 = locs.unsqueeze(0) if squeeze else locs
+    l3 = l3.contiguous().float()
+    N, P, _ = l3.shape
+    out = torch.empty_like(l3)
+    _lib.check(ctx.lib.od_decode_locs(ctx.handle, l3.data_ptr(), priors.data_ptr(), out.data_ptr(), N, P,
+                                      float(loc_scale), int(clip), _stream_ptr()), "od_decode_locs")
+    return out[0] if squeeze else out

@@ -1,0 +1,129 @@
+"""GPU parity: od_conv2d_fwd / od_conv_first_fwd (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Tolerance: inputs and weights are f16-representable, the kernel accumulates in f32 and rounds ONCE to f16, so the
+result must equal the f64 oracle rounded to f16 up to 1 f16 ulp (rtol 2^-10) + accumulation-order noise (atol 1e-3
+relative to the output scale, the tolerance north_star states for logits).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import network as onet
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, scale, bias, stride, act, alpha, res=None, up2=False):
+    y = onet.conv_nhwc(x, w, stride, torch.float64).astype(np.float64)
+    y = y * scale.astype(np.float64) + bias.astype(np.float64)
+    if act == "leaky":
+        y = np.where(y > 0, y, y * alpha)
+    elif act == "elu":
+        y = np.where(y > 0, y, alpha * np.expm1(np.minimum(y, 0)))
+    if res is not None:
+        r = res.astype(np.float64)
+        if up2:
+            r = np.repeat(np.repeat(r, 2, axis=1), 2, axis=2)
+        y = y + r
+    return y
+
+
+CASES = [
+    # B, H, W, Cin, Cout, k, stride, act, res, cfg
+    (2, 16, 16, 32, 64, 3, 1, "leaky", "same", -1),     # Cin=32: per-lane tap path, K tail (288 -> 320)
+    (2, 16, 16, 64, 128, 3, 2, "leaky", "none", -1),    # stride 2
+    (3, 10, 10, 128, 64, 1, 1, "leaky", "none", -1),    # 1x1, M=300 (ragged M edge)
+    (1, 8, 8, 64, 32, 1, 1, "leaky", "none", -1),       # Cout=32 < BN
+    (2, 12, 20, 256, 256, 3, 1, "elu", "up2", -1),      # neck lateral-style, non-square
+    (2, 10, 10, 512, 1024, 3, 1, "leaky", "same", -1),  # long K
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 0),
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 1),
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 2),
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 3),
+    (1, 4, 4, 8, 8, 3, 1, None, "none", -1),             # tiny everything: Cin=8, single partial tile
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_conv_matches_oracle(cuda, case):
+    from object_detector_amd import ops
+    B, H, W, Cin, Cout, k, stride, act, resm, cfg = case
+    rng = np.random.default_rng(hash(case) & 0xFFFF)
+    x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float16)
+    w = (rng.normal(0, 1, (Cout, k, k, Cin)) * np.sqrt(2.0 / (k * k * Cin))).astype(np.float16)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    bias = rng.normal(0, 0.1, Cout).astype(np.float32)
+    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    res = None
+    if resm == "same":
+        res = rng.normal(0, 1, (B, Ho, Wo, Cout)).astype(np.float16)
+    elif resm == "up2":
+        res = rng.normal(0, 1, (B, Ho // 2, Wo // 2, Cout)).astype(np.float16)
+    alpha = 0.1 if act == "leaky" else 1.0
+    xt = torch.from_numpy(x).to(cuda)
+    rt = torch.from_numpy(res).to(cuda) if res is not None else None
+    out = ops.conv2d(xt, w.astype(np.float32), scale, bias, stride=stride, act=act, alpha=alpha, res=rt,
+                     res_mode=resm, tile_cfg=cfg)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().astype(np.float64)
+    ref = _ref(x.astype(np.float32), w.astype(np.float32), scale, bias, stride, act, alpha,
+               None if res is None else res.astype(np.float32), resm == "up2")
+    assert got.shape == ref.shape
+    err = np.abs(got - ref)
+    tol = 1e-3 * max(1.0, np.abs(ref).max()) + 2.0 ** -10 * np.abs(ref)
+    assert (err <= tol).all(), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
+
+
+def test_conv_f32_strided_output(cuda):
+    """prediction conv: Cout=208 (not a tile multiple), f32 logits written into a slice of pred[B,P,26]."""
+    from object_detector_amd import ops
+    rng = np.random.default_rng(7)
+    B, H, W, Cin, Cout = 2, 10, 10, 256, 208
+    P_total, C = 3000, 26
+    off = 400  # rows
+    x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float16)
+    w = (rng.normal(0, 1, (Cout, 3, 3, Cin)) * 0.02).astype(np.float16)
+    bias = rng.normal(0, 0.1, Cout).astype(np.float32)
+    pred = torch.full((B, P_total, C), 7.0, dtype=torch.float32, device=cuda)
+    sl = pred.view(-1)[off * C:]
+    ops.conv2d(torch.from_numpy(x).to(cuda), w.astype(np.float32), np.ones(Cout, np.float32), bias, out_f32=True,
+               out=sl, out_batch_stride=P_total * C, out_pix_stride=Cout)
+    torch.cuda.synchronize()
+    got = pred.cpu().numpy()
+    ref = _ref(x.astype(np.float32), w.astype(np.float32), np.ones(Cout), bias, 1, None, 0.0).reshape(B, H * W * 8, C)
+    np.testing.assert_allclose(got[:, off:off + H * W * 8], ref, rtol=1e-4, atol=1e-4)
+    assert (got[:, :off] == 7.0).all() and (got[:, off + H * W * 8:] == 7.0).all()  # nothing else touched
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32), (1, 40, 72), (3, 8, 32)])
+def test_conv_first_matches_oracle(cuda, shape):
+    from object_detector_amd import ops
+    B, H, W = shape
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    w = (rng.normal(0, 1, (32, 3, 3, 3)) * np.sqrt(2.0 / 27)).astype(np.float16)
+    scale = (rng.uniform(0.5, 1.5, 32) / 255.0).astype(np.float32)
+    bias = rng.normal(0, 0.1, 32).astype(np.float32)
+    out = ops.conv_first(torch.from_numpy(x).to(cuda), w.astype(np.float32), scale, bias, "leaky", 0.1)
+    torch.cuda.synchronize()
+    ref = _ref(x.astype(np.float32), w.astype(np.float32), scale, bias, 1, "leaky", 0.1)
+    got = out.cpu().numpy().astype(np.float64)
+    err = np.abs(got - ref)
+    assert (err <= 1e-3 + 2.0 ** -10 * np.abs(ref)).all(), err.max()
+
+
+def test_upsample2x_add(cuda):
+    from object_detector_amd import ops
+    rng = np.random.default_rng(5)
+    a = rng.normal(0, 1, (2, 8, 12, 64)).astype(np.float16)
+    u = rng.normal(0, 1, (2, 4, 6, 64)).astype(np.float16)
+    out = ops.upsample2x_add(torch.from_numpy(a).to(cuda), torch.from_numpy(u).to(cuda)).cpu().numpy()
+    ref = (a.astype(np.float32) + np.repeat(np.repeat(u, 2, 1), 2, 2).astype(np.float32)).astype(np.float16)
+    assert (out == ref).all()
+
+
+def test_conv_rejects_bad_args(cuda):
+    from object_detector_amd import ops, _lib
+    x = torch.zeros((1, 4, 4, 6), dtype=torch.float16, device=cuda)  # Cin % 8 != 0
+    with pytest.raises(_lib.OdError):
+        ops.conv2d(x, np.zeros((8, 3, 3, 6), np.float32), np.ones(8), np.zeros(8))
