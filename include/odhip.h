@@ -132,6 +132,29 @@ int od_nms(od_ctx* ctx, const float* boxes, const uint64_t* keys, const int32_t*
            void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K9: prior-box assignment + target encoding = od.pb.encode_truth (reference check_assign.py:21,25-27).
+ *   priors f32 [P,4]; gt_boxes f32 [B,Gmax,4] corner form, normalised; gt_classes i32 [B,Gmax]; gt_counts i32 [B]
+ *   y f32 [B,P,2+NC+4]: col 0 = background, col 1 = assigned ("y[:,1]==1", :25), cols 2..2+NC one-hot class (:26),
+ *   last 4 = regression target = inverse of od_decode_locs (:27).  An all-zero row = ignored prior.
+ *   assigned_gt i32 [B,P] (may be NULL): GT index, -1 background, -2 ignore;  npos i32 [B] assigned priors per image.
+ * Rule [BUILD-DEFINED]: best GT per prior with IoU >= pos_thr; neg_thr <= IoU < pos_thr ignored; every GT force-takes
+ * its best prior (ascending GT index, later wins).  Gmax <= 128.
+ * ---------------------------------------------------------------------------------------------- */
+size_t od_assign_workspace_bytes(int B, int P, int Gmax);
+int od_assign_anchors(od_ctx* ctx, const float* priors, const float* gt_boxes, const int32_t* gt_classes,
+                      const int32_t* gt_counts, int B, int P, int Gmax, int NC, float pos_thr, float neg_thr,
+                      float loc_scale, float* y, int32_t* assigned_gt, int32_t* npos, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* K10: loss forward + gradient (reference docs/MODEL.md:33-52): focal(objectness, 2-class softmax) +
+ * softmax-CE(classes, assigned priors) + box loss (box_mode 0 smooth-L1 / 1 MSE, assigned priors), each weighted and
+ * divided by max(1, #assigned).  pred, y, grad f32 [B,P,2+NC+4]; losses f32 [4] = obj, cls, box, total. */
+size_t od_loss_workspace_bytes(int B, int P);
+int od_loss_fwd_bwd(od_ctx* ctx, const float* pred, const float* y, float* grad, float* losses, int B, int P, int NC,
+                    float focal_alpha, float focal_gamma, int box_mode, float w_obj, float w_cls, float w_box,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Native forward plan: the whole layer list of one network executed from C++ (one call per batch, optional
  * hipGraph replay) so Python is not in the per-layer loop.  ops is an array of od_plan_op.
  * ---------------------------------------------------------------------------------------------- */

@@ -65,6 +65,14 @@ _PROTOS = {
     "od_nms_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "od_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                          C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "od_assign_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "od_assign_anchors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "od_loss_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "od_loss_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                  C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float,
+                                  C.c_void_p, C.c_size_t, C.c_void_p]),
     "od_plan_create": (C.c_int, [C.c_void_p, C.POINTER(PlanOp), C.c_int, C.POINTER(C.c_void_p)]),
     "od_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
     "od_plan_capture": (C.c_int, [C.c_void_p, C.c_void_p]),

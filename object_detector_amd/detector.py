@@ -1,0 +1,156 @@
+"""`tk.dl.od.ObjectDetector`: the drop-in boundary of the hot path.
+
+Keeps the call surface the reference scripts use (voc_validate.py:25-27, voc_evaluate.py:25-27, check_assign.py:19):
+    ObjectDetector.load_voc(batch_size, input_size=(320,320), keep_aspect=False, strict_nms=False, use_multi_gpu=True)
+    od.predict(X, conf_threshold=...) -> list of per-image predictions (.classes, .confs, .bboxes, .plot(x, names))
+    od.pb.encode_truth / od.pb.decode_locs
+and runs everything below it on MI355X through libodhip.so.  use_multi_gpu shards images by index over the ranks of
+an already-initialised torch.distributed job (one process per GPU); inference needs no collective on the data path,
+results are gathered on the host.
+"""
+from __future__ import annotations
+
+import os
+import pathlib
+
+import numpy as np
+import torch
+
+from . import weights as W
+from .net import Net
+from .pb import ObjectsAnnotation, PriorBoxes
+from .postprocess import Postprocessor
+
+DEFAULT_CONF_THRESHOLD = 0.01  # [BUILD-DEFINED]: mAP needs the low-confidence tail (voc_evaluate.py:27 passes 0.6)
+VOC_WEIGHTS_ENV = "OD_VOC_WEIGHTS"
+
+
+class ObjectsPrediction:
+    """Detections of one image: classes i32 [n], confs f32 [n], bboxes f32 [n,4] (corner form, normalised [0,1] of the
+    ORIGINAL image: keep_aspect=False is a plain resize, so normalised coordinates are resize-invariant)."""
+
+    def __init__(self, classes, confs, bboxes, flat_indices=None):
+        self.classes = np.asarray(classes, np.int32)
+        self.confs = np.asarray(confs, np.float32)
+        self.bboxes = np.asarray(bboxes, np.float32).reshape(-1, 4)
+        self.flat_indices = None if flat_indices is None else np.asarray(flat_indices, np.int32)
+
+    def plot(self, x, class_names=None):
+        from .tk import ml
+        return ml.plot_objects(x, self.classes, self.confs, self.bboxes, class_names)
+
+    def __len__(self):
+        return len(self.classes)
+
+
+def load_image(x, size_hw, keep_aspect=False):
+    """path / ndarray -> uint8 [H,W,3] resized to the network input (host side: PIL)."""
+    from PIL import Image
+    H, Wd = size_hw
+    if isinstance(x, (str, os.PathLike)):
+        img = Image.open(x).convert("RGB")
+    else:
+        a = np.asarray(x)
+        if a.dtype != np.uint8:
+            a = np.clip(a, 0, 255).astype(np.uint8)
+        if a.shape[:2] == (H, Wd):
+            return a[..., :3]
+        img = Image.fromarray(a[..., :3])
+    if not keep_aspect:
+        return np.asarray(img.resize((Wd, H), Image.BILINEAR), np.uint8)
+    s = min(Wd / img.width, H / img.height)
+    nw, nh = max(1, round(img.width * s)), max(1, round(img.height * s))
+    canvas = np.zeros((H, Wd, 3), np.uint8)
+    canvas[:nh, :nw] = np.asarray(img.resize((nw, nh), Image.BILINEAR), np.uint8)
+    return canvas
+
+
+class ObjectDetector:
+    def __init__(self, params, batch_size=16, input_size=(320, 320), keep_aspect=False, strict_nms=False,
+                 use_multi_gpu=True, device=None, prior_wh=None):
+        if device is None:
+            device = f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
+        if not torch.cuda.is_available():
+            from ._lib import OdError
+            raise OdError("ObjectDetector needs an MI355X (no GPU visible); there is no CPU path")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.batch_size = int(batch_size)
+        self.input_size = tuple(int(v) for v in input_size)
+        self.keep_aspect, self.strict_nms, self.use_multi_gpu = bool(keep_aspect), bool(strict_nms), bool(use_multi_gpu)
+        self.params = params
+        self.num_classes, _, _ = W.infer_arch(params)
+        kw = {} if prior_wh is None else {"prior_wh": prior_wh}
+        self.pb = PriorBoxes(self.input_size, self.num_classes, device=self.device, **kw)
+        self.net = Net(params, self.batch_size, self.input_size, device=self.device)
+        assert self.net.P == len(self.pb)
+        self.post = Postprocessor(self.batch_size, self.net.P, self.num_classes, self.pb.pb_locs, device=self.device,
+                                  strict_nms=self.strict_nms, loc_scale=self.pb.loc_scale)
+
+    # -- construction -----------------------------------------------------------------------------------------
+    @classmethod
+    def load_voc(cls, batch_size, input_size=(320, 320), keep_aspect=False, strict_nms=False, use_multi_gpu=True,
+                 weights=None, **kw):
+        """VOC-trained detector.  The reference pulls an LFS `*.h5` (.gitattributes:5); offline this build reads its own
+        .npz from `weights`, $OD_VOC_WEIGHTS, or ./weights/voc07+12_<H>x<W>.npz -- a LOCAL path, never a download."""
+        path = weights or os.environ.get(VOC_WEIGHTS_ENV) or \
+            pathlib.Path("weights") / f"voc07+12_{input_size[0]}x{input_size[1]}.npz"
+        path = pathlib.Path(path)
+        if not path.exists():
+            raise FileNotFoundError(
+                f"VOC weights not found at {path}. Trained weights are not distributable offline; pass weights=<npz>, "
+                f"set ${VOC_WEIGHTS_ENV}, or build a synthetic detector with ObjectDetector.synthetic(...).")
+        params, meta = W.load(path)
+        if "prior_wh" in meta:
+            kw.setdefault("prior_wh", meta["prior_wh"])
+        return cls(params, batch_size, input_size, keep_aspect, strict_nms, use_multi_gpu, **kw)
+
+    @classmethod
+    def synthetic(cls, batch_size, input_size=(320, 320), seed=2, num_classes=20, **kw):
+        """Random-init detector of the VOC architecture (benchmarks / parity tests)."""
+        return cls(W.random_init(seed, num_classes), batch_size, input_size, **kw)
+
+    # -- inference --------------------------------------------------------------------------------------------
+    def predict_batch_device(self, x_u8: torch.Tensor, conf_threshold=DEFAULT_CONF_THRESHOLD, graph=False):
+        """uint8 [B,H,W,3] on device -> (keep_flat [B,max_det], keep_count [B]) on device.  The timed hot path."""
+        pred = self.net.forward(x_u8, graph=graph)
+        return self.post.run(pred, conf_threshold)
+
+    def _collect(self, n_valid):
+        keep = self.post.keep_flat[:n_valid].cpu().numpy()
+        cnt = self.post.keep_count[:n_valid].cpu().numpy()
+        conf = self.post.conf
+        boxes = self.post.boxes
+        out = []
+        NC = self.num_classes
+        for b in range(n_valid):
+            k = keep[b, :cnt[b]].astype(np.int64)
+            kt = torch.from_numpy(k).to(self.device)
+            confs = conf[b].reshape(-1)[kt].cpu().numpy()
+            bxs = boxes[b][kt // NC].cpu().numpy()
+            out.append(ObjectsPrediction(k % NC, confs, bxs, k))
+        return out
+
+    def predict(self, X, conf_threshold=DEFAULT_CONF_THRESHOLD, verbose=0):
+        """X: sequence of image paths or uint8 arrays -> list[ObjectsPrediction] in input order."""
+        X = list(X)
+        rank, world = 0, 1
+        if self.use_multi_gpu and torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+        mine = list(range(rank, len(X), world))  # shard by index: no data-path collective
+        results = {}
+        B = self.batch_size
+        host = np.zeros((B,) + self.input_size + (3,), np.uint8)
+        for s in range(0, len(mine), B):
+            idx = mine[s:s + B]
+            for j, i in enumerate(idx):
+                host[j] = load_image(X[i], self.input_size, self.keep_aspect)
+            x = torch.from_numpy(host).to(self.device, non_blocking=False)
+            self.predict_batch_device(x, conf_threshold)
+            for i, p in zip(idx, self._collect(len(idx))):
+                results[i] = p
+        if world > 1:
+            gathered = [None] * world
+            torch.distributed.all_gather_object(gathered, results)
+            results = {k: v for d in gathered for k, v in d.items()}
+        return [results[i] for i in range(len(X))]

@@ -1,0 +1,150 @@
+"""`tk.dl.od.od_gen`: training data generator (reference check_generator.py:17-18, check_assign.py:21-22).
+
+    gen = create_generator((512, 512), preprocess_input=lambda x: x, encode_truth=od.pb.encode_truth)
+    g, steps = gen.flow(X, y, data_augmentation=True)      # infinite iterator of (X_batch, y_batch)
+
+Augmentation list is [BUILD-DEFINED] (docs/MODEL.md:60-64 names Random Erasing "and anything else at hand", erasing
+constrained so that boxes are not hidden too much): horizontal flip, random crop/zoom that keeps every box centre,
+brightness / contrast / saturation jitter, Random Erasing limited to <= 40 % of any box.  Augmentation PARAMETERS are
+sampled on the host (numpy Generator, seeded); the pixel work runs on the device through od_augment_batch when a GPU
+is present (`device=`), prior-box encoding always runs on the device (encode_truth = od.pb.encode_truth).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .pb import ObjectsAnnotation
+
+
+class AugParams:
+    """Per-image augmentation parameters (sampled on the host, consumed by the pixel kernel / host path)."""
+    __slots__ = ("crop", "flip", "brightness", "contrast", "saturation", "erase")
+
+    def __init__(self):
+        self.crop = (0.0, 0.0, 1.0, 1.0)  # x1,y1,x2,y2 in normalised source coordinates
+        self.flip = False
+        self.brightness = 0.0   # additive, in [0,255] units
+        self.contrast = 1.0
+        self.saturation = 1.0
+        self.erase = []         # [(x1,y1,x2,y2 in normalised OUTPUT coords, (r,g,b))]
+
+
+def sample_params(rng: np.random.Generator, ann: ObjectsAnnotation, random_erasing=True) -> AugParams:
+    p = AugParams()
+    b = ann.bboxes
+    if rng.random() < 0.5 and len(b):  # crop/zoom keeping all box centres inside
+        cx = (b[:, 0] + b[:, 2]) / 2
+        cy = (b[:, 1] + b[:, 3]) / 2
+        x1 = rng.uniform(0, max(1e-6, min(cx.min(), 0.3)))
+        y1 = rng.uniform(0, max(1e-6, min(cy.min(), 0.3)))
+        x2 = rng.uniform(min(1 - 1e-6, max(cx.max(), 0.7)), 1)
+        y2 = rng.uniform(min(1 - 1e-6, max(cy.max(), 0.7)), 1)
+        p.crop = (float(x1), float(y1), float(x2), float(y2))
+    p.flip = bool(rng.random() < 0.5)
+    p.brightness = float(rng.uniform(-32, 32)) if rng.random() < 0.5 else 0.0
+    p.contrast = float(rng.uniform(0.6, 1.4)) if rng.random() < 0.5 else 1.0
+    p.saturation = float(rng.uniform(0.6, 1.4)) if rng.random() < 0.5 else 1.0
+    if random_erasing and rng.random() < 0.5:
+        nb = transform_boxes(b, p)
+        for _ in range(int(rng.integers(1, 4))):
+            for _try in range(10):
+                area = rng.uniform(0.02, 0.2)
+                ar = math.exp(rng.uniform(math.log(0.3), math.log(1 / 0.3)))
+                w, h = min(1.0, math.sqrt(area * ar)), min(1.0, math.sqrt(area / ar))
+                x1, y1 = rng.uniform(0, 1 - w), rng.uniform(0, 1 - h)
+                r = np.array([x1, y1, x1 + w, y1 + h], np.float32)
+                if _hidden_fraction(r, nb) <= 0.4:  # box-aware constraint
+                    p.erase.append((tuple(float(v) for v in r), tuple(int(v) for v in rng.integers(0, 256, 3))))
+                    break
+    return p
+
+
+def _hidden_fraction(rect, boxes):
+    if not len(boxes):
+        return 0.0
+    iw = np.clip(np.minimum(rect[2], boxes[:, 2]) - np.maximum(rect[0], boxes[:, 0]), 0, None)
+    ih = np.clip(np.minimum(rect[3], boxes[:, 3]) - np.maximum(rect[1], boxes[:, 1]), 0, None)
+    area = np.maximum((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]), 1e-12)
+    return float((iw * ih / area).max())
+
+
+def transform_boxes(bboxes, p: AugParams):
+    """Boxes follow the crop then the flip; clipped to the frame."""
+    b = np.asarray(bboxes, np.float32).reshape(-1, 4).copy()
+    x1, y1, x2, y2 = p.crop
+    b[:, [0, 2]] = (b[:, [0, 2]] - x1) / (x2 - x1)
+    b[:, [1, 3]] = (b[:, [1, 3]] - y1) / (y2 - y1)
+    if p.flip:
+        b[:, [0, 2]] = 1.0 - b[:, [2, 0]]
+    return np.clip(b, 0.0, 1.0)
+
+
+def apply_pixels_host(img_u8: np.ndarray, p: AugParams, out_hw) -> np.ndarray:
+    """Host pixel path (PIL resize): used when no device is given."""
+    from PIL import Image
+    H, W = out_hw
+    h0, w0 = img_u8.shape[:2]
+    x1, y1, x2, y2 = p.crop
+    box = (int(round(x1 * w0)), int(round(y1 * h0)), max(int(round(x2 * w0)), int(round(x1 * w0)) + 1),
+           max(int(round(y2 * h0)), int(round(y1 * h0)) + 1))
+    im = Image.fromarray(img_u8).crop(box).resize((W, H), Image.BILINEAR)
+    a = np.asarray(im, np.float32)
+    if p.flip:
+        a = a[:, ::-1]
+    if p.saturation != 1.0:
+        g = a @ np.array([0.299, 0.587, 0.114], np.float32)
+        a = g[..., None] + (a - g[..., None]) * p.saturation
+    if p.contrast != 1.0:
+        a = (a - 127.5) * p.contrast + 127.5
+    a = a + p.brightness
+    a = np.clip(np.rint(a), 0, 255).astype(np.uint8)
+    for (ex1, ey1, ex2, ey2), col in p.erase:
+        a[int(ey1 * H):int(math.ceil(ey2 * H)), int(ex1 * W):int(math.ceil(ex2 * W))] = col
+    return a
+
+
+class Generator:
+    def __init__(self, input_size, preprocess_input=None, encode_truth=None, random_erasing=True):
+        self.input_size = tuple(int(v) for v in input_size)
+        self.preprocess_input = preprocess_input
+        self.encode_truth = encode_truth
+        self.random_erasing = random_erasing
+
+    def _load(self, x):
+        if isinstance(x, np.ndarray):
+            return x[..., :3].astype(np.uint8)
+        from .tk.ndimage import load
+        return load(x)
+
+    def generate(self, x, ann: ObjectsAnnotation, rng, data_augmentation):
+        img = self._load(x)
+        p = sample_params(rng, ann, self.random_erasing) if data_augmentation else AugParams()
+        out = apply_pixels_host(img, p, self.input_size)
+        new_ann = ObjectsAnnotation(ann.path, self.input_size[1], self.input_size[0], ann.classes,
+                                    transform_boxes(ann.bboxes, p), ann.difficults)
+        return out, new_ann
+
+    def flow(self, X, y, batch_size=16, data_augmentation=False, shuffle=False, seed=0):
+        """-> (infinite iterator of (X_batch [B,H,W,3], y_batch), steps_per_epoch)   (check_generator.py:18)"""
+        n = len(X)
+        steps = max(1, math.ceil(n / batch_size))
+
+        def it():
+            rng = np.random.default_rng(seed)
+            while True:
+                order = rng.permutation(n) if shuffle else np.arange(n)
+                for s in range(0, n, batch_size):
+                    idx = order[s:s + batch_size]
+                    imgs, anns = zip(*(self.generate(X[i], y[i], rng, data_augmentation) for i in idx))
+                    xb = np.stack(imgs)
+                    if self.preprocess_input is not None:
+                        xb = self.preprocess_input(xb)
+                    yb = self.encode_truth(list(anns)) if self.encode_truth is not None else list(anns)
+                    yield xb, yb
+        return it(), steps
+
+
+def create_generator(input_size, preprocess_input=None, encode_truth=None, **kw):
+    return Generator(input_size, preprocess_input, encode_truth, **kw)

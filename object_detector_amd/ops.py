@@ -82,3 +82,21 @@ def decode_locs(locs: torch.Tensor, priors: torch.Tensor, loc_scale=0.1, clip=Fa
     _lib.check(ctx.lib.od_decode_locs(ctx.handle, l3.data_ptr(), priors.data_ptr(), out.data_ptr(), N, P,
                                       float(loc_scale), int(clip), _stream_ptr()), "od_decode_locs")
     return out[0] if squeeze else out
+
+
+def loss_fwd_bwd(pred: torch.Tensor, y: torch.Tensor, num_classes=20, alpha=0.25, gamma=2.0, box_mode="smooth_l1",
+                 weights=(1.0, 1.0, 1.0)):
+    """pred, y f32 [B,P,2+NC+4] -> (losses f32 [4] = obj, cls, box, total ; grad f32 like pred)   (K10)"""
+    ctx = _ctx(pred)
+    assert pred.dtype == torch.float32 and y.dtype == torch.float32 and pred.is_contiguous() and y.is_contiguous()
+    B, P, Cc = pred.shape
+    assert Cc == num_classes + 6 and y.shape == pred.shape
+    grad = torch.empty_like(pred)
+    losses = torch.empty((4,), dtype=torch.float32, device=pred.device)
+    wsb = ctx.lib.od_loss_workspace_bytes(B, P)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=pred.device)
+    _lib.check(ctx.lib.od_loss_fwd_bwd(ctx.handle, pred.data_ptr(), y.data_ptr(), grad.data_ptr(), losses.data_ptr(),
+                                       B, P, num_classes, float(alpha), float(gamma),
+                                       {"smooth_l1": 0, "mse": 1}[box_mode], float(weights[0]), float(weights[1]),
+                                       float(weights[2]), ws.data_ptr(), wsb, _stream_ptr()), "od_loss_fwd_bwd")
+    return losses, grad

@@ -1,0 +1,83 @@
+"""GPU end-to-end parity: the native forward plan (Darknet53 + neck + shared prediction module) and the whole
+predict path vs the CPU oracle, same seeded weights and images.
+
+Tolerances (north_star: 1e-3 on logits, bit-exact kept indices):
+  * vs the oracle with f16 storage at the SAME rounding points (storage="f16"): |dlogit| <= 1e-3 * max(1, max|logit|)
+  * vs the plain fp32-activation oracle: reported, bounded at 2e-2 * scale (f16 activation storage is the design
+    point of the path -- DESIGN.md "numerics"); never used to claim index parity
+  * kept indices: bit-exact vs oracle NMS fed the device's own (conf, boxes); and equal to the full-oracle result
+    whenever no candidate's confidence gap is below the logit tolerance
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import network as onet
+from oracle import nms as onms
+from oracle import postprocess as opp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small_setup(cuda):
+    from object_detector_amd import weights as W
+    from object_detector_amd.net import Net
+    params = W.random_init(seed=2)
+    B, S = 2, 96
+    net = Net(params, B, (S, S), device=cuda)
+    x = onet.synthetic_images(B, S, seed=0)
+    pred = net.forward(torch.from_numpy(x).to(cuda)).clone()
+    torch.cuda.synchronize()
+    return params, net, x, pred.cpu().numpy()
+
+
+def test_logits_vs_f16_storage_oracle(small_setup):
+    params, net, x, got = small_setup
+    ref = onet.Runner(params, storage="f16").forward(x)
+    assert got.shape == ref.shape
+    scale = max(1.0, np.abs(ref).max())
+    err = np.abs(got - ref).max()
+    assert err <= 1e-3 * scale, (err, scale)
+
+
+def test_logits_vs_fp32_oracle(small_setup):
+    params, net, x, got = small_setup
+    ref = onet.Runner(params, storage="f32").forward(x)
+    scale = max(1.0, np.abs(ref).max())
+    err = np.abs(got - ref).max()
+    print(f"max |logit - fp32 oracle| = {err:.3e} (scale {scale:.2f})")
+    assert err <= 2e-2 * scale
+
+
+def test_graph_replay_matches_eager(small_setup, cuda):
+    params, net, x, got = small_setup
+    xt = torch.from_numpy(x).to(cuda)
+    a = net.forward(xt, graph=True).clone()
+    b = net.forward(xt, graph=True).clone()
+    torch.cuda.synchronize()
+    assert (a.cpu().numpy() == got).all() and (b.cpu().numpy() == got).all()
+
+
+def test_predict_end_to_end(cuda):
+    from object_detector_amd.detector import ObjectDetector
+    B, S = 2, 160
+    od = ObjectDetector.synthetic(B, (S, S), seed=2, device=cuda)
+    x = onet.synthetic_images(B, S, seed=0)
+    keep, cnt = od.predict_batch_device(torch.from_numpy(x).to(cuda), conf_threshold=0.01)
+    torch.cuda.synchronize()
+    keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+    conf, boxes = od.post.conf.cpu().numpy(), od.post.boxes.cpu().numpy()
+    for b in range(B):
+        ref, *_ = onms.detect_image(conf[b], boxes[b], K=1024, conf_threshold=0.01, iou_threshold=0.45, max_det=200)
+        assert cnt[b] == len(ref) and (keep[b, :len(ref)] == ref).all()
+    # public API on arrays: same result, classes/confs/bboxes consistent with the flat indices
+    preds = od.predict(list(x), conf_threshold=0.01)
+    for b, p in enumerate(preds):
+        assert (p.flat_indices == keep[b, :cnt[b]]).all()
+        assert (p.classes == p.flat_indices % 20).all()
+        assert (p.confs == conf[b].reshape(-1)[p.flat_indices]).all()
+        assert (np.diff(p.confs) <= 0).all()
+    # conf_threshold=0.6 (voc_evaluate.py:27) on random weights: nothing (or few) survives, still well-formed
+    hi = od.predict(list(x), conf_threshold=0.6)
+    assert all(len(p) <= 200 and (p.confs > 0.6).all() for p in hi)
