@@ -65,6 +65,30 @@ def load_image(x, size_hw, keep_aspect=False):
     return canvas
 
 
+def dist_info(use_multi_gpu=True):
+    """(rank, world) of the torch.distributed job this process belongs to (one process per GPU), else (0, 1)."""
+    if use_multi_gpu and torch.distributed.is_available() and torch.distributed.is_initialized():
+        return torch.distributed.get_rank(), torch.distributed.get_world_size()
+    return 0, 1
+
+
+def shard_indices(n, rank, world):
+    """Images are independent: rank r takes indices r, r+world, ... -- no collective on the data path."""
+    return list(range(rank, n, world))
+
+
+def gather_results(local: dict, world: int) -> dict:
+    """Host-side gather of the per-rank {index: prediction} maps (variable-length results; every rank gets all)."""
+    if world <= 1:
+        return local
+    gathered = [None] * world
+    torch.distributed.all_gather_object(gathered, local)
+    out = {}
+    for d in gathered:
+        out.update(d)
+    return out
+
+
 class ObjectDetector:
     def __init__(self, params, batch_size=16, input_size=(320, 320), keep_aspect=False, strict_nms=False,
                  use_multi_gpu=True, device=None, prior_wh=None):
@@ -134,10 +158,8 @@ class ObjectDetector:
     def predict(self, X, conf_threshold=DEFAULT_CONF_THRESHOLD, verbose=0):
         """X: sequence of image paths or uint8 arrays -> list[ObjectsPrediction] in input order."""
         X = list(X)
-        rank, world = 0, 1
-        if self.use_multi_gpu and torch.distributed.is_available() and torch.distributed.is_initialized():
-            rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
-        mine = list(range(rank, len(X), world))  # shard by index: no data-path collective
+        rank, world = dist_info(self.use_multi_gpu)
+        mine = shard_indices(len(X), rank, world)
         results = {}
         B = self.batch_size
         host = np.zeros((B,) + self.input_size + (3,), np.uint8)
@@ -149,8 +171,5 @@ class ObjectDetector:
             self.predict_batch_device(x, conf_threshold)
             for i, p in zip(idx, self._collect(len(idx))):
                 results[i] = p
-        if world > 1:
-            gathered = [None] * world
-            torch.distributed.all_gather_object(gathered, results)
-            results = {k: v for d in gathered for k, v in d.items()}
+        results = gather_results(results, world)
         return [results[i] for i in range(len(X))]

@@ -1,0 +1,202 @@
+"""CPU: host-side logic of the product package (no kernels run here): the C ABI library loads and exports every
+symbol include/odhip.h declares, prior table, VOC loader/evaluator, score report, generator, API surface."""
+import ctypes
+import pathlib
+import re
+
+import numpy as np
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def _header_functions():
+    txt = (ROOT / "include" / "odhip.h").read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(od_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_header_symbol():
+    from object_detector_amd import _lib
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    names = _header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/odhip.h but not exported by libodhip.so"
+    assert set(names) == set(_lib.EXPORTED_SYMBOLS), set(names) ^ set(_lib.EXPORTED_SYMBOLS)
+    lib2 = _lib.load()
+    assert lib2.od_version() >= 100
+    a, b = _lib.conv_weight_dims(208, 256, 3)
+    assert (a, b) == (256, 2304)
+    assert _lib.conv_weight_dims(64, 32, 3) == (128, 320)  # K tail padded to the 64-deep step
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from object_detector_amd import _lib
+    with pytest.raises(_lib.OdError, match="no CPU fallback"):
+        _lib.load(tmp_path / "libodhip.so")
+
+
+def test_no_gpu_no_cpu_path():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from object_detector_amd import _lib
+    from object_detector_amd.detector import ObjectDetector
+    with pytest.raises(_lib.OdError):
+        ObjectDetector.synthetic(1, (64, 64))
+
+
+def test_product_never_imports_oracle():
+    for f in (ROOT / "object_detector_amd").rglob("*.py"):
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", f.read_text(), flags=re.M), f
+    assert not re.search(r"^\s*(from|import)\s+oracle\b", (ROOT / "pytoolkit" / "__init__.py").read_text(), flags=re.M)
+
+
+def test_priors_match_oracle_and_layout():
+    from object_detector_amd import priors as PR
+    from oracle import postprocess as opp
+    for size in [(320, 320), (640, 640), (256, 384)]:
+        assert (PR.make_priors(size) == opp.make_priors(size)).all()
+    pr = PR.make_priors((320, 320))
+    assert pr.shape == (16800, 4)
+    # level-major, then y, x, prior: first cell's 8 priors share a centre
+    c = (pr[:8, :2] + pr[:8, 2:]) / 2
+    assert np.allclose(c, c[0]) and np.allclose(c[0], 0.5 / 40)
+
+
+def test_prior_fit_kmeans():
+    from object_detector_amd import priors as PR
+    rng = np.random.default_rng(1)
+    c = rng.uniform(0.2, 0.8, (600, 2))
+    wh = np.exp(rng.uniform(np.log(0.05), np.log(0.9), (600, 2)))
+    b = np.clip(np.concatenate([c - wh / 2, c + wh / 2], 1), 0, 1)
+    t = PR.fit(b, (320, 320))
+    assert t.shape == (3, 8, 2) and (t > 0).all()
+    assert PR.make_priors((320, 320), t).shape == (16800, 4)
+
+
+def test_weights_roundtrip_and_specs(tmp_path):
+    from object_detector_amd import weights as W
+    from oracle import network as onet
+    specs = W.layer_specs()
+    assert specs == onet.layer_specs()
+    assert sum(1 for s in specs if s[0].startswith("b.")) == 52  # Darknet53 conv count
+    n_backbone = sum(co * ci * k * k for (nm, ci, co, k, s, bn) in specs if nm.startswith("b."))
+    assert abs(n_backbone - 40.55e6) < 0.05e6
+    flops320 = 0
+    h = 320
+    for nm, ci, co, k, s, bn in specs:
+        if not nm.startswith("b."):
+            continue
+        h = h // s
+        flops320 += 2 * h * h * co * ci * k * k
+    assert abs(flops320 - 29.01e9) < 0.02e9
+    p = {"a.w": np.ones((2, 1, 1, 8), np.float32), "a.bias": np.zeros(2, np.float32)}
+    W.save(tmp_path / "w.npz", p, {"prior_wh": np.ones((3, 8, 2))})
+    q, meta = W.load(tmp_path / "w.npz")
+    assert set(q) == set(p) and (q["a.w"] == p["a.w"]).all() and meta["prior_wh"].shape == (3, 8, 2)
+    prm = W.random_init(2)
+    ref = onet.init_weights(2)
+    assert all((prm[k] == ref[k]).all() for k in ref) and W.infer_arch(prm) == (20, 256, 1)
+
+
+def _write_voc(root, n=3):
+    from PIL import Image
+    base = root / "VOC2007"
+    for d in ("Annotations", "JPEGImages", "ImageSets/Main"):
+        (base / d).mkdir(parents=True, exist_ok=True)
+    ids = []
+    for i in range(n):
+        name = f"{i:06d}"
+        ids.append(name)
+        Image.fromarray(np.full((100, 200, 3), 40 * i, np.uint8)).save(base / "JPEGImages" / f"{name}.jpg")
+        (base / "Annotations" / f"{name}.xml").write_text(f"""<annotation><filename>{name}.jpg</filename>
+<size><width>200</width><height>100</height><depth>3</depth></size>
+<object><name>dog</name><difficult>0</difficult><bndbox><xmin>21</xmin><ymin>11</ymin><xmax>120</xmax><ymax>90</ymax></bndbox></object>
+<object><name>person</name><difficult>{i % 2}</difficult><bndbox><xmin>101</xmin><ymin>1</ymin><xmax>200</xmax><ymax>100</ymax></bndbox></object>
+</annotation>""")
+    (base / "ImageSets" / "Main" / "test.txt").write_text("\n".join(ids))
+
+
+def test_voc_loader(tmp_path):
+    import pytoolkit as tk
+    _write_voc(tmp_path)
+    X, y = tk.data.voc.load_07_test(tmp_path)
+    assert len(X) == len(y) == 3 and X[0].stem == "000000" and isinstance(X[0], pathlib.Path)
+    a = y[1]
+    assert a.classes.tolist() == [tk.data.voc.CLASS_NAMES.index("dog"), tk.data.voc.CLASS_NAMES.index("person")]
+    np.testing.assert_allclose(a.bboxes[0], [0.1, 0.1, 0.6, 0.9])
+    assert a.difficults.tolist() == [False, True]
+    assert len(tk.data.voc.CLASS_NAMES) == 20
+
+
+def test_voc_evaluate_hand_cases():
+    import pytoolkit as tk
+    from object_detector_amd.detector import ObjectsPrediction
+    from object_detector_amd.pb import ObjectsAnnotation
+    gt = [ObjectsAnnotation(None, 100, 100, [0, 0], [[0.1, 0.1, 0.4, 0.4], [0.5, 0.5, 0.9, 0.9]]),
+          ObjectsAnnotation(None, 100, 100, [1], [[0.2, 0.2, 0.8, 0.8]])]
+    perfect = [ObjectsPrediction([0, 0], [0.9, 0.8], gt[0].bboxes), ObjectsPrediction([1], [0.7], gt[1].bboxes)]
+    s = tk.data.voc.evaluate(gt, perfect)
+    assert s["mAP"] == pytest.approx(1.0) and s["mAP_VOC"] == pytest.approx(1.0)
+    # class 0: detections ranked TP, FP, TP -> prec at recall .5 = 1, at recall 1 = 2/3
+    pred = [ObjectsPrediction([0, 0, 0], [0.9, 0.8, 0.7], [gt[0].bboxes[0], [0.0, 0.6, 0.1, 0.7], gt[0].bboxes[1]]),
+            ObjectsPrediction([], [], np.zeros((0, 4)))]
+    s = tk.data.voc.evaluate(gt, pred)
+    ap0_int = 0.5 * 1.0 + 0.5 * (2 / 3)
+    ap0_11 = (6 * 1.0 + 5 * (2 / 3)) / 11
+    assert s["mAP"] == pytest.approx((ap0_int + 0.0) / 2)
+    assert s["mAP_VOC"] == pytest.approx((ap0_11 + 0.0) / 2)
+    p, r, f, sup = tk.ml.compute_scores(gt, pred, iou_threshold=0.5, num_classes=2)
+    assert p[0] == pytest.approx(2 / 3) and r[0] == pytest.approx(1.0) and sup.tolist() == [2, 1] and r[1] == 0
+    lines = []
+    tk.ml.print_scores(p, r, f, sup, ["a", "b"], print_fn=lines.append)
+    assert len(lines) == 4
+
+
+def test_generator_host_path(tmp_path):
+    """reference check_generator.py:17-22 call shapes; boxes track the pixels through flip/crop."""
+    import pytoolkit as tk
+    _write_voc(tmp_path)
+    X, y = tk.data.voc.load_07_test(tmp_path)
+    gen = tk.dl.od.od_gen.create_generator((64, 96), preprocess_input=lambda x: x, encode_truth=None)
+    g, steps = gen.flow(X, y, batch_size=2, data_augmentation=True, seed=3)
+    assert steps == 2
+    for _i, (xb, yb) in zip(range(4), g):
+        assert xb.dtype == np.uint8 and xb.shape[1:] == (64, 96, 3) and len(yb) == len(xb)
+        for a in yb:
+            assert hasattr(a, "classes") and hasattr(a, "bboxes")
+            assert (a.bboxes >= 0).all() and (a.bboxes <= 1).all() and (a.bboxes[:, 2:] >= a.bboxes[:, :2]).all()
+    from object_detector_amd import od_gen
+    p = od_gen.AugParams()
+    p.flip, p.crop = True, (0.1, 0.2, 0.9, 1.0)
+    b = od_gen.transform_boxes(np.array([[0.1, 0.2, 0.5, 0.6]], np.float32), p)
+    np.testing.assert_allclose(b, [[0.5, 0.0, 1.0, 0.5]], atol=1e-6)
+    img = tk.ml.plot_objects(xb[0], yb[0].classes, None, yb[0].bboxes, tk.data.voc.CLASS_NAMES)
+    tk.ndimage.save(tmp_path / "o" / "x.jpg", img)
+    assert (tmp_path / "o" / "x.jpg").exists()
+
+
+def test_tk_surface_matches_reference_scripts():
+    """every tk.* symbol the four reference scripts touch exists."""
+    import pytoolkit as tk
+    for path in ["better_exceptions", "dl.session", "log.init", "log.trace", "log.get", "tqdm", "ndimage.save",
+                 "data.voc.load_07_test", "data.voc.evaluate", "data.voc.CLASS_NAMES", "ml.compute_scores",
+                 "ml.print_scores", "ml.plot_objects", "dl.od.ObjectDetector", "dl.od.od_gen.create_generator"]:
+        o = tk
+        for part in path.split("."):
+            o = getattr(o, part)
+    OD = tk.dl.od.ObjectDetector
+    import inspect
+    sig = inspect.signature(OD.load_voc)
+    for kw in ("batch_size", "input_size", "keep_aspect", "strict_nms", "use_multi_gpu"):
+        assert kw in sig.parameters
+    assert "conf_threshold" in inspect.signature(OD.predict).parameters
+    with pytest.raises(FileNotFoundError):
+        OD.load_voc(batch_size=1, use_multi_gpu=False, weights="/nonexistent/voc.npz")
+
+    @tk.log.trace()
+    def f(v):
+        return v + 1
+    assert f(1) == 2

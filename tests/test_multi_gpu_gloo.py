@@ -1,0 +1,44 @@
+"""CPU, world_size 2, gloo: the N>1 inference path = shard images by index, no data-path collective, host gather
+(reference knob: use_multi_gpu=True, voc_validate.py:26).  The per-rank device work is replaced by a stub so that
+the sharding / gathering / ordering logic is what is under test."""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from object_detector_amd.detector import ObjectsPrediction, dist_info, gather_results, shard_indices
+        assert dist_info(True) == (rank, world) and dist_info(False) == (0, 1)
+        mine = shard_indices(n, rank, world)
+        local = {i: ObjectsPrediction([i % 20] * (i % 3), [0.5] * (i % 3), np.full((i % 3, 4), i, np.float32), None)
+                 for i in mine}
+        allr = gather_results(local, world)
+        assert sorted(allr) == list(range(n))
+        ok = all((allr[i].bboxes == i).all() and len(allr[i]) == i % 3 for i in range(n))
+        q.put((rank, mine, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_predict_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n, world, port = 11, 2, 29731
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    res.sort()
+    assert res[0][1] == list(range(0, n, 2)) and res[1][1] == list(range(1, n, 2))
+    assert all(r[2] for r in res)
+    # every image is processed exactly once
+    assert sorted(res[0][1] + res[1][1]) == list(range(n))

@@ -1,0 +1,125 @@
+"""CPU: the oracle reproduces its committed golden vectors and is cross-checked against independent restatements
+(torch conv vs an explicit-tap f64 einsum, analytic gradient vs finite differences, fp32 vs fp64 evaluation)."""
+import pathlib
+
+import numpy as np
+import pytest
+
+from oracle import assign as oassign
+from oracle import loss as oloss
+from oracle import network as onet
+from oracle import nms as onms
+from oracle import postprocess as opp
+
+G = pathlib.Path(__file__).parent / "golden"
+
+
+def _load(name):
+    with np.load(G / name, allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("tag", ["c3x3_s1", "c3x3_s2", "c1x1"])
+def test_conv_golden_torch_vs_einsum(tag):
+    d = _load(f"conv_{tag}.npz")
+    act = bytes(d["act"]).decode()
+    import torch
+    y = onet.conv_nhwc(d["x"].astype(np.float32), d["w"].astype(np.float32), int(d["stride"]), torch.float64)
+    y = y * d["scale"] + d["bias"]
+    a = 0.1 if act == "leaky" else 1.0
+    y = np.where(y > 0, y, y * a) if act == "leaky" else np.where(y > 0, y, a * np.expm1(np.minimum(y, 0)))
+    y = (y + d["res"].astype(np.float64)).astype(np.float16)
+    # the golden y came from the independent einsum path: equal up to 1 f16 ulp of rounding-boundary noise
+    diff = np.abs(y.astype(np.float32) - d["y"].astype(np.float32))
+    assert (diff <= 2.0 ** -9 * np.maximum(1.0, np.abs(d["y"].astype(np.float32)))).all()
+    assert (diff == 0).mean() > 0.99
+
+
+@pytest.mark.parametrize("size", [320, 640])
+def test_priors_golden(size):
+    d = _load(f"priors_{size}.npz")
+    pr = opp.make_priors((size, size))
+    assert len(pr) == int(d["count"]) == 8 * ((size // 8) ** 2 + (size // 16) ** 2 + (size // 32) ** 2)
+    assert (pr[:64] == d["head"]).all() and (pr[-64:] == d["tail"]).all()
+    assert pr.astype(np.float64).sum() == pytest.approx(float(d["sum"]), rel=1e-12)
+    assert len(pr) == {320: 16800, 640: 67200}[size]
+
+
+def test_net_golden():
+    d = _load("net_64.npz")
+    params = onet.init_weights(seed=2)
+    assert sum(float(np.abs(v).sum()) for v in params.values()) == pytest.approx(float(d["w_checksum"]), rel=1e-9)
+    pred = onet.Runner(params, storage="f16").forward(d["x"])
+    # oneDNN may pick another accumulation order on another host: allow f32-sum noise, not more
+    np.testing.assert_allclose(pred, d["pred_f16storage"], rtol=0, atol=2e-3)
+    p64 = onet.Runner(params, storage="f32", precise=True).forward(d["x"])
+    np.testing.assert_allclose(p64, d["pred_f32"], rtol=0, atol=1e-3)
+    assert pred.shape == (1, 8 * (64 + 16 + 4), 26)
+
+
+def test_post_nms_golden():
+    d = _load("post_nms_64.npz")
+    conf, boxes = opp.head_postprocess(d["pred"], d["priors"])
+    assert (boxes == d["boxes"]).all()
+    np.testing.assert_allclose(conf, d["conf"], rtol=1e-6)
+    for b in range(2):
+        k, *_ = onms.detect_image(d["conf"][b], d["boxes"][b], K=256, conf_threshold=0.01, iou_threshold=0.45, max_det=100)
+        ref = d["keep"][b]
+        assert (k == ref[ref >= 0]).all()
+
+
+def test_assign_loss_golden():
+    d = _load("assign_loss_128.npz")
+    pr = opp.make_priors((128, 128))
+    y, a = oassign.encode_truth(d["gt_boxes"], d["gt_classes"], pr, 20)
+    assert (y == d["y"]).all() and (a == d["assigned"]).all()
+    losses, grad = oloss.loss_and_grad(d["pred"], y, 20)
+    np.testing.assert_allclose(losses, d["losses"], rtol=1e-12)
+    np.testing.assert_allclose(grad, d["grad"], rtol=1e-5, atol=1e-9)
+
+
+def test_loss_gradient_finite_difference():
+    rng = np.random.default_rng(0)
+    pr = opp.make_priors((64, 64))
+    y, a = oassign.encode_truth(np.array([[0.1, 0.1, 0.6, 0.7]], np.float32), [4], pr, 20)
+    pred = rng.normal(0, 1, y.shape)
+    for mode in ("smooth_l1", "mse"):
+        L, g = oloss.loss_and_grad(pred, y, 20, box_mode=mode)
+        rows = list(np.nonzero(a >= 0)[0][:2]) + list(np.nonzero(a == -1)[0][:1])
+        for r in rows:
+            for c in (0, 1, 3, 22, 25):
+                p2 = pred.copy()
+                p2[r, c] += 1e-6
+                L2, _ = oloss.loss_and_grad(p2, y, 20, box_mode=mode)
+                assert (L2[3] - L[3]) / 1e-6 == pytest.approx(g[r, c], rel=2e-3, abs=1e-7)
+
+
+def test_nms_hand_case():
+    """three same-class boxes: B overlaps A (IoU .68 > .45) -> suppressed; C disjoint; other class never suppressed."""
+    boxes = np.array([[0.1, 0.1, 0.5, 0.5], [0.15, 0.15, 0.55, 0.55], [0.6, 0.6, 0.9, 0.9], [0.1, 0.1, 0.5, 0.5]], np.float32)
+    conf = np.zeros((4, 20), np.float32)
+    conf[0, 3], conf[1, 3], conf[2, 3], conf[3, 5] = 0.9, 0.8, 0.7, 0.85
+    keep, cls, cf, bx = onms.detect_image(conf, boxes)
+    assert keep.tolist() == [0 * 20 + 3, 3 * 20 + 5, 2 * 20 + 3]
+    keep_s, *_ = onms.detect_image(conf, boxes, strict=True)
+    assert keep_s.tolist() == [3, 2 * 20 + 3]  # class-agnostic: box 3 (same coords as 0) is suppressed too
+
+
+def test_nms_tie_order_lowest_index_first():
+    boxes = np.tile(np.array([[0.1, 0.1, 0.2, 0.2]], np.float32), (5, 1)) + np.arange(5, dtype=np.float32)[:, None] * 0.15
+    boxes = np.clip(boxes, 0, 1)
+    conf = np.full((5, 20), 0.0, np.float32)
+    conf[:, 2] = 0.5  # all equal
+    keys = onms.topk_keys(conf.reshape(-1), 3, 0.01)
+    flat = (np.uint64(0xFFFFFFFF) - (keys & np.uint64(0xFFFFFFFF))).astype(int)
+    assert flat.tolist() == [2, 22, 42]
+
+
+def test_decode_zero_is_prior_and_encode_roundtrip():
+    pr = opp.make_priors((96, 96))
+    assert (opp.decode_locs(np.zeros_like(pr), pr) == pr).all()  # reference check_assign.py:27
+    gt = np.array([[0.2, 0.25, 0.7, 0.8]], np.float32)
+    y, a = oassign.encode_truth(gt, [1], pr, 20)
+    pos = a >= 0
+    assert pos.sum() >= 1 and (y[pos, 1] == 1).all() and (y[pos, 2 + 1] == 1).all() and (y[~pos, 1] == 0).all()
+    np.testing.assert_allclose(opp.decode_locs(y[:, -4:], pr)[pos], np.repeat(gt, pos.sum(), 0), atol=2e-6)
