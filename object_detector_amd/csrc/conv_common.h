@@ -1,0 +1,145 @@
+// Shared by the convolution translation units (conv_mfma.hip: implicit GEMM; conv_win.hip: LDS-window direct 3x3).
+#pragma once
+#include "common.h"
+
+struct ConvKP {
+  const f16* x;
+  const f16* w;
+  const float* scale;
+  const float* bias;
+  const f16* res;
+  void* out;
+  const f16* zero;
+  int H, W, Cin, Ho, Wo, Cout;
+  int stride, pad;
+  int Kstride, Ktot, M, HoWo;
+  int act;
+  float alpha;
+  int res_mode, out_f32;
+  long long obs, ops;
+  int mtiles, ntiles;
+  int dbg;  // tuning ablations (OD_CONV_DEBUG): bit0 = skip the DMA, bit1 = skip fragment reads + MFMA
+};
+
+static __device__ __forceinline__ void glds16(const void* gptr, void* lptr) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                   (__attribute__((address_space(3))) void*)lptr, 16, 0, 0);
+}
+
+template <int N>
+static __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+
+// ---- epilogue shared by every conv kernel: accumulators -> LDS staging (one wave-row of the tile at a time) ->
+//      scale/bias/act (+ residual) in f32 on full NHWC lines, ONE rounding to f16, 16-B stores.
+//      acc[i][j][e] holds pixel (wave-row base + i*16 + l15), channel (wn*WTN + j*16 + lq*4 + e).
+template <int BN, int WM, int WN, int MT, int NTL, int NT = WM * WN * 64>
+static __device__ __forceinline__ void conv_epilogue(const ConvKP& p, char* smem, f32x4 (&acc)[MT][NTL], int m0, int n0,
+                                                     int tid, int wm, int wn, int l15, int lq) {
+  constexpr int WTM = MT * 16, WTN = NTL * 16, SLD = BN + 4;
+  float* stg = (float*)smem;
+  constexpr int CH = BN / 8;    // 8-channel chunks per row
+  constexpr int RPP = NT / CH;  // rows per store pass
+  const int c8 = (tid % CH) * 8;
+  const int n = n0 + c8;
+  float sc[8], bi[8];
+  {
+    const f32x4 s0 = *(const f32x4*)(p.scale + n), s1 = *(const f32x4*)(p.scale + n + 4);
+    const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sc[e] = s0[e];
+      sc[4 + e] = s1[e];
+      bi[e] = b0[e];
+      bi[4 + e] = b1[e];
+    }
+  }
+  // residual rows are fetched up front (one 16-B load per store pass, all in flight together) so that their HBM/L2
+  // latency overlaps the LDS staging instead of serialising pass after pass
+  constexpr int NPASS = WTM / RPP;
+  f16x8 resv[WM][NPASS];
+  if (p.res_mode != OD_RES_NONE) {
+#pragma unroll
+    for (int wr = 0; wr < WM; ++wr)
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int m = m0 + wr * WTM + ps * RPP + tid / CH;
+        f16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (m < p.M && n < p.Cout) {
+          long long roff;
+          if (p.res_mode == OD_RES_SAME) {
+            roff = (long long)m * p.Cout + n;
+          } else {
+            const unsigned b = (unsigned)m / (unsigned)p.HoWo;
+            const unsigned pix = (unsigned)m - b * (unsigned)p.HoWo;
+            const unsigned ho = pix / (unsigned)p.Wo, wo = pix - ho * (unsigned)p.Wo;
+            roff = ((long long)(b * (unsigned)(p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout + n;
+          }
+          r = *(const f16x8*)(p.res + roff);
+        }
+        resv[wr][ps] = r;
+      }
+  }
+#pragma unroll
+  for (int wr = 0; wr < WM; ++wr) {
+    if (wm == wr) {
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) {
+        const int nl = wn * WTN + j * 16 + lq * 4;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) *(f32x4*)(stg + (i * 16 + l15) * SLD + nl) = acc[i][j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int row = ps * RPP + tid / CH;
+      const int m = m0 + wr * WTM + row;
+      if (m < p.M && n < p.Cout) {
+        const f32x4 v0 = *(const f32x4*)(stg + row * SLD + c8);
+        const f32x4 v1 = *(const f32x4*)(stg + row * SLD + c8 + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
+        if (p.act == OD_ACT_LEAKY) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+        } else if (p.act == OD_ACT_ELU) {
+#pragma unroll 1
+          for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : p.alpha * expm1f(v[e]);
+        }
+        if (p.res_mode != OD_RES_NONE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)resv[wr][ps][e];
+        }
+        const unsigned b = (unsigned)m / (unsigned)p.HoWo;
+        const unsigned pix = (unsigned)m - b * (unsigned)p.HoWo;
+        const long long ooff = (long long)b * p.obs + (long long)pix * p.ops + n;
+        if (p.out_f32) {
+          float* o = (float*)p.out + ooff;
+          *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
+          *(f32x4*)(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          f16x8 h;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) h[e] = (f16)v[e];
+          *(f16x8*)((f16*)p.out + ooff) = h;
+        }
+      }
+    }
+    if (wr + 1 < WM) __syncthreads();
+  }
+}
+
+// a launchable convolution kernel variant
+struct ConvKernelInfo {
+  const void* fn;
+  const char* name;
+  int BM, BN, threads;
+};
+
+// conv_win.hip: LDS-window direct 3x3 / stride-1 kernels.  Returns false when the shape cannot use variant `idx`.
+int od_conv_win_num_cfgs();
+bool od_conv_win_select(int idx, const ConvKP& p, ConvKernelInfo* info, size_t* lds_bytes);

@@ -3,68 +3,68 @@
 //   C[n, m] = sum_k W[n, k] * X[m, k]      m = (b, ho, wo) output pixel, n = output channel,
 //                                          k = (dy*KS + dx)*Cin + cin  (never materialised)
 //
-// One 256-thread workgroup (4 waves) owns a BM x BN output tile.  Per 64-deep K step it gathers the BM x 64
-// activation slice and the BN x 64 weight slice straight into LDS with global_load_lds_dwordx4 (LDS-DMA, 16 B per
-// lane, per-lane SOURCE address = the shifted input pixel, or the context's zero page for padding / tails), double
-// buffered so the DMA of step k+1 overlaps the MFMAs of step k.  LDS rows are 128 B; 16-B chunk c of row r lives at
-// chunk c ^ (r & 7) (swizzle applied on the source side of the DMA and on the ds_read_b128 side), which makes the
-// fragment reads bank-conflict free.  v_mfma_f32_16x16x32_f16 runs with the WEIGHTS as the A operand so that each
-// lane ends up with 4 consecutive output channels of one pixel; the epilogue applies scale/bias/activation in f32,
-// stages the tile through LDS and writes full NHWC lines (16 B per lane) with the residual added in f32 and ONE
-// rounding to f16.
+// One workgroup (4 or 8 waves) owns a BM x BN output tile.  Per BK-deep K step it gathers the BM x BK activation
+// slice and the BN x BK weight slice straight into LDS with global_load_lds_dwordx4 (LDS-DMA, 16 B per lane, per-lane
+// SOURCE address = the shifted input pixel, or the context's zero page for padding / tails).  The LDS is a ring of
+// STAGES buffers; loads run STAGES-1 steps ahead of the MFMAs and are retired with a COUNTED s_waitcnt vmcnt(N) + one
+// raw s_barrier per step (never vmcnt(0) in the steady state), so the HBM/L2 latency of the gather is covered by
+// STAGES-2 whole K steps of matrix work.  LDS images are bank-conflict free for ds_read_b128 fragment reads:
+//   BK = 64: 128-B rows, 16-B chunk c of row r at chunk c ^ (r & 7)      (swizzle applied on the DMA source side)
+//   BK = 32: per 16-row piece, chunk-major [chunk][row]                  (the DMA lane picks (row, chunk) to match)
+// v_mfma_f32_16x16x32_f16 runs with the WEIGHTS as the A operand so that each lane ends up with 4 consecutive output
+// channels of one pixel; the epilogue applies scale/bias/activation in f32, stages the tile through LDS and writes full
+// NHWC lines (16 B per lane) with the residual added in f32 and ONE rounding to f16.
 //
 // Replaces the Conv2D + BatchNormalization + LeakyReLU/ELU (+ Add) layers executed inside
 // `ObjectDetector.predict` (reference voc_validate.py:27; docs/MODEL.md:5-21).
-#include "common.h"
+#include <stdlib.h>
+
+#include "conv_common.h"
 
 namespace {
 
-constexpr int BK = 64;        // K elements per step
-constexpr int ROW_BYTES = 128;  // BK * sizeof(f16)
-
-struct ConvKP {
-  const f16* x;
-  const f16* w;
-  const float* scale;
-  const float* bias;
-  const f16* res;
-  void* out;
-  const f16* zero;
-  int H, W, Cin, Ho, Wo, Cout;
-  int stride, pad;
-  int Kpad, Ktot, M, HoWo;
-  int act;
-  float alpha;
-  int res_mode, out_f32, cin64;
-  long long obs, ops;
-  int mtiles, ntiles;
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, int SPEC = 0>
+struct ConvCfg {
+  static constexpr int NT = WM * WN * 64;            // threads of one role (consumers; = loaders when SPEC)
+  static constexpr int NTHREADS = NT * (SPEC ? 2 : 1);
+  static constexpr int CPR = BK / 8;    // 16-B chunks per row
+  static constexpr int RPR = NT / CPR;  // rows covered by one DMA round of the whole workgroup
+  static constexpr int AR = BM / RPR, BR = BN / RPR;
+  static constexpr int ROWB = BK * 2;
+  static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int WTM = BM / WM, WTN = BN / WN;
+  static constexpr int MT = WTM / 16, NTL = WTN / 16;
+  static constexpr int SLD = BN + 4;  // epilogue staging row stride (floats)
+  static constexpr int PIPE_BYTES = STAGES * STAGE_BYTES;
+  static constexpr int EPI_BYTES = WTM * SLD * 4;
+  static constexpr int LDS_BYTES = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
+  static constexpr int LOADS = AR + BR;  // LDS-DMA instructions per wave per K step
+  static_assert(BM % RPR == 0 && BN % RPR == 0, "tile must be a whole number of DMA rounds");
+  static_assert(BK == 32 || BK == 64, "BK");
+  static_assert(LOADS * (STAGES - 2 > 0 ? STAGES - 2 : 0) <= 63, "vmcnt field");
 };
 
-__device__ __forceinline__ void glds16(const void* gptr, void* lptr) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
-                                   (__attribute__((address_space(3))) void*)lptr, 16, 0, 0);
-}
-
-__device__ __forceinline__ float od_act(float v, int act, float alpha) {
-  if (act == OD_ACT_LEAKY) return v > 0.f ? v : v * alpha;
-  if (act == OD_ACT_ELU) return v > 0.f ? v : alpha * expm1f(v);
-  return v;
-}
-
-template <int BM, int BN, int WM, int WN, int KS>
-__global__ __launch_bounds__(256, 2) void od_conv_igemm(ConvKP p) {
-  static_assert(WM * WN == 4, "4 waves");
-  constexpr int WTM = BM / WM, WTN = BN / WN;
-  constexpr int MT = WTM / 16, NT = WTN / 16;
-  constexpr int AR = BM / 32, BR = BN / 32;  // glds rounds (32 rows of 128 B per round per workgroup)
-  constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int SLD = BN + 4;  // epilogue staging row stride in floats
+// UNI: every BK-deep K step lies inside ONE filter tap (Cin % BK == 0; always true for KS == 1 with Cin % BK == 0):
+// the tap walk is then wave-uniform scalar state advanced incrementally, and per-row padding validity is a 9-bit mask
+// computed once.  UNI = false keeps a per-lane k -> (tap, cin) decomposition for odd channel counts.
+// SPEC: wave specialisation.  The workgroup has 2 x WM*WN waves: the first half only runs MFMAs (consumers), the second
+// half only issues the LDS-DMA (loaders) -- an LDS-DMA instruction costs its issuing wave ~70 cycles, which otherwise
+// comes straight out of the MFMA stream.  Both halves meet at the same per-step barrier.
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, int KS, int MINW, bool UNI, int SPEC>
+__global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), MINW) void od_conv_igemm(ConvKP p) {
+  using Cf = ConvCfg<BM, BN, BK, STAGES, WM, WN, SPEC>;
+  constexpr int NT = Cf::NT, AR = Cf::AR, BR = Cf::BR, RPR = Cf::RPR, ROWB = Cf::ROWB;
+  constexpr int WTM = Cf::WTM, WTN = Cf::WTN, MT = Cf::MT, NTL = Cf::NTL, SLD = Cf::SLD;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid_all = threadIdx.x;
+  const int lane = tid_all & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid_all >> 6);
+  const bool is_loader = SPEC ? (wave_all >= WM * WN) : true;
+  const bool is_consumer = SPEC ? (wave_all < WM * WN) : true;
+  const int tid = SPEC ? (tid_all & (NT - 1)) : tid_all;   // index inside the role
+  const int wave = SPEC ? (wave_all >= WM * WN ? wave_all - WM * WN : wave_all) : wave_all;
   const int l15 = lane & 15, lq = lane >> 4;
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous run of logical tiles,
@@ -80,12 +80,22 @@ __global__ __launch_bounds__(256, 2) void od_conv_igemm(ConvKP p) {
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- per-lane gather state --------------------------------------------------------------------------------
-  const int rr = tid >> 3;              // row within a 32-row round
-  const int lc = (tid & 7) ^ (rr & 7);  // logical 16-B chunk this lane fetches (source-side swizzle)
+  int rr, lc, piece_off;  // row inside a DMA round, logical 16-B chunk fetched, LDS byte offset of this wave's piece
+  if (BK == 64) {
+    rr = tid >> 3;
+    lc = (tid & 7) ^ (rr & 7);
+    piece_off = wave * 8 * ROWB;
+  } else {
+    rr = wave * 16 + (lane & 15);
+    lc = lane >> 4;
+    piece_off = wave * 16 * ROWB;
+  }
   int a_base[AR], a_hi0[AR], a_wi0[AR];
+  unsigned a_vmask[AR];  // UNI: bit t = tap t reads inside the image for this row
 #pragma unroll
   for (int rd = 0; rd < AR; ++rd) {
-    const int m = m0 + rd * 32 + rr;
+    const int m = m0 + rd * RPR + rr;
+    a_vmask[rd] = 0u;
     if (m < p.M) {
       const unsigned b = (unsigned)m / (unsigned)p.HoWo;
       const unsigned pix = (unsigned)m - b * (unsigned)p.HoWo;
@@ -93,196 +103,223 @@ __global__ __launch_bounds__(256, 2) void od_conv_igemm(ConvKP p) {
       const unsigned wo = pix - ho * (unsigned)p.Wo;
       a_hi0[rd] = (int)ho * p.stride - p.pad;
       a_wi0[rd] = (int)wo * p.stride - p.pad;
-      a_base[rd] = (((int)b * p.H + a_hi0[rd]) * p.W + a_wi0[rd]) * p.Cin;
+      a_base[rd] = (((int)b * p.H + a_hi0[rd]) * p.W + a_wi0[rd]) * p.Cin + lc * 8;
+#pragma unroll
+      for (int t = 0; t < KS * KS; ++t) {
+        const int hi = a_hi0[rd] + t / KS, wi = a_wi0[rd] + t % KS;
+        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) a_vmask[rd] |= 1u << t;
+      }
     } else {
       a_hi0[rd] = -(1 << 24);
       a_wi0[rd] = 0;
       a_base[rd] = 0;
     }
   }
-  const f16* wrow = p.w + (long long)(n0 + rr) * p.Kpad + lc * 8;
+  const f16* wrow = p.w + (long long)(n0 + rr) * p.Kstride + lc * 8;
 
-  auto stage = [&](int ks, int buf) {
-    char* abuf = smem + buf * STAGE_BYTES;
-    char* bbuf = abuf + A_BYTES;
-    const int k0 = ks * BK;
-    int dy = 0, dx = 0, cin, kvalid;
-    if (KS == 1) {
-      cin = k0 + lc * 8;
-      kvalid = cin < p.Cin;
-    } else if (p.cin64) {
-      const int tap = k0 / p.Cin;  // wave-uniform: a 64-deep step never straddles a tap
-      dy = tap / 3;
-      dx = tap - dy * 3;
-      cin = k0 - tap * p.Cin + lc * 8;
-      kvalid = 1;
+  // loader state: the NEXT step to stage (steps are staged strictly in order) -- all wave-uniform scalars
+  int ld_k0 = 0, ld_c0 = 0, ld_tap = 0, ld_tapoff = 0, ld_dx = 0;
+
+  auto stage = [&](int buf) {
+    if (p.dbg & 1) return;
+    char* abuf = smem + buf * Cf::STAGE_BYTES + piece_off;
+    char* bbuf = abuf + Cf::A_BYTES;
+    if (UNI) {
+      const bool cvalid = (KS == 3) || (ld_c0 + lc * 8 < p.Cin);
+      const int koff = ld_tapoff + ld_c0;  // scalar: (dy*W + dx)*Cin + c0
+#pragma unroll
+      for (int rd = 0; rd < AR; ++rd) {
+        const bool ok = cvalid && ((a_vmask[rd] >> ld_tap) & 1u);
+        const f16* src = ok ? p.x + (a_base[rd] + koff) : p.zero;
+        glds16(src, abuf + rd * RPR * ROWB);
+      }
     } else {
-      const int k = k0 + lc * 8;
+      const int k = ld_k0 + lc * 8;
       const int tap = k / p.Cin;
-      dy = tap / 3;
-      dx = tap - dy * 3;
-      cin = k - tap * p.Cin;
-      kvalid = k < p.Ktot;
-    }
-    const int koff = (dy * p.W + dx) * p.Cin + cin;
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const int cin = k - tap * p.Cin;
+      const bool kvalid = k < p.Ktot;
+      const int koff = (dy * p.W + dx) * p.Cin + cin - lc * 8;
 #pragma unroll
-    for (int rd = 0; rd < AR; ++rd) {
-      const int hi = a_hi0[rd] + dy, wi = a_wi0[rd] + dx;
-      const bool ok = kvalid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      const f16* src = ok ? p.x + (a_base[rd] + koff) : p.zero;
-      glds16(src, abuf + (rd * 32 + wave * 8) * ROW_BYTES);
+      for (int rd = 0; rd < AR; ++rd) {
+        const int hi = a_hi0[rd] + dy, wi = a_wi0[rd] + dx;
+        const bool ok = kvalid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        const f16* src = ok ? p.x + (a_base[rd] + koff) : p.zero;
+        glds16(src, abuf + rd * RPR * ROWB);
+      }
     }
 #pragma unroll
-    for (int rd = 0; rd < BR; ++rd) {
-      glds16(wrow + (long long)rd * 32 * p.Kpad + k0, bbuf + (rd * 32 + wave * 8) * ROW_BYTES);
+    for (int rd = 0; rd < BR; ++rd) glds16(wrow + (long long)rd * RPR * p.Kstride + ld_k0, bbuf + rd * RPR * ROWB);
+    // advance to the next step
+    ld_k0 += BK;
+    if (UNI) {
+      ld_c0 += BK;
+      if (KS == 3 && ld_c0 >= p.Cin) {
+        ld_c0 = 0;
+        ++ld_tap;
+        if (++ld_dx == 3) {
+          ld_dx = 0;
+          ld_tapoff += (p.W - 2) * p.Cin;
+        } else {
+          ld_tapoff += p.Cin;
+        }
+      }
     }
   };
 
-  // ---- main loop ----------------------------------------------------------------------------------------------
+  // ---- main loop: STAGES-deep LDS ring, counted vmcnt, one raw barrier per K step ------------------------------
   const int wm = wave / WN, wn = wave - wm * WN;
-  f32x4 acc[MT][NT];
+  f32x4 acc[MT][NTL];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.Kpad / BK;
-  stage(0, 0);
-  __syncthreads();  // emits vmcnt(0): step-0 DMA landed
+  const int nk = (p.Ktot + BK - 1) / BK;
+  if (is_loader) {
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+      if (s < nk) stage(s);
+  }
+
   const int swz = l15 & 7;
+  int buf = 0;
   for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nk) stage(ks + 1, buf ^ 1);
-    const char* abuf = smem + buf * STAGE_BYTES;
-    const char* bbuf = abuf + A_BYTES;
+    // retire this step's DMA (issued STAGES-1 steps ago); later steps stay in flight
+    if ((p.dbg & 4) || !is_loader) {
+      // consumers have no DMA of their own; dbg bit 2: never wait for the DMA (garbage results, timing ablation)
+    } else if (STAGES > 2 && ks + (STAGES - 2) < nk) {
+      wait_vmcnt<Cf::LOADS*(STAGES > 2 ? STAGES - 2 : 0)>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();  // every wave's piece of step ks landed; everyone finished reading step ks-1
+    {
+      const int nxt = ks + STAGES - 1;
+      int nb = buf + STAGES - 1;
+      if (nb >= STAGES) nb -= STAGES;
+      if (is_loader && nxt < nk) stage(nb);  // overwrites the buffer read at step ks-1
+    }
+    const char* abuf = smem + buf * Cf::STAGE_BYTES;
+    const char* bbuf = abuf + Cf::A_BYTES;
+    __builtin_amdgcn_s_setprio(1);
+    if (is_consumer && !(p.dbg & 2))
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-      const int coff = ((kh * 4 + lq) ^ swz) * 16;
-      f16x8 xa[MT], wb[NT];
+    for (int kh = 0; kh < BK / 32; ++kh) {
+      f16x8 xa[MT], wb[NTL];
+      if (BK == 64) {
+        const int coff = ((kh * 4 + lq) ^ swz) * 16;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) xa[i] = *(const f16x8*)(abuf + (wm * WTM + i * 16 + l15) * ROWB + coff);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) wb[j] = *(const f16x8*)(bbuf + (wn * WTN + j * 16 + l15) * ROWB + coff);
+      } else {
+        const int coff = lq * 256 + l15 * 16;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) xa[i] = *(const f16x8*)(abuf + (wm * WTM + i * 16) * ROWB + coff);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) wb[j] = *(const f16x8*)(bbuf + (wn * WTN + j * 16) * ROWB + coff);
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
-        xa[i] = *(const f16x8*)(abuf + (wm * WTM + i * 16 + l15) * ROW_BYTES + coff);
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        wb[j] = *(const f16x8*)(bbuf + (wn * WTN + j * 16 + l15) * ROW_BYTES + coff);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NTL; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();  // next buffer landed (vmcnt(0)) and everyone is done reading this one
+    __builtin_amdgcn_s_setprio(0);
+    if (++buf == STAGES) buf = 0;
   }
+  __syncthreads();  // all fragment reads done before the ring is reused as epilogue staging
 
-  // ---- epilogue: scale/bias/act in f32 -> LDS staging -> full-line stores (+ residual) -------------------------
-  float* stg = (float*)smem;
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int nl = wn * WTN + j * 16 + lq * 4;
-    const f32x4 sc = *(const f32x4*)(p.scale + n0 + nl);
-    const f32x4 bi = *(const f32x4*)(p.bias + n0 + nl);
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int ml = wm * WTM + i * 16 + l15;
-      f32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = od_act(acc[i][j][e] * sc[e] + bi[e], p.act, p.alpha);
-      *(f32x4*)(stg + ml * SLD + nl) = v;
-    }
-  }
-  __syncthreads();
-
-  constexpr int CH = BN / 8;     // 8-channel chunks per row
-  constexpr int RPP = 256 / CH;  // rows per pass
-  const int c8 = (tid % CH) * 8;
-  const int n = n0 + c8;
-#pragma unroll
-  for (int ps = 0; ps < BM / RPP; ++ps) {
-    const int row = ps * RPP + tid / CH;
-    const int m = m0 + row;
-    if (m < p.M && n < p.Cout) {
-      const f32x4 v0 = *(const f32x4*)(stg + row * SLD + c8);
-      const f32x4 v1 = *(const f32x4*)(stg + row * SLD + c8 + 4);
-      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      const unsigned b = (unsigned)m / (unsigned)p.HoWo;
-      const unsigned pix = (unsigned)m - b * (unsigned)p.HoWo;
-      if (p.res_mode != OD_RES_NONE) {
-        long long roff;
-        if (p.res_mode == OD_RES_SAME) {
-          roff = (long long)m * p.Cout + n;
-        } else {
-          const unsigned ho = pix / (unsigned)p.Wo, wo = pix - ho * (unsigned)p.Wo;
-          roff = ((long long)(b * (unsigned)(p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout + n;
-        }
-        const f16x8 r = *(const f16x8*)(p.res + roff);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
-      }
-      const long long ooff = (long long)b * p.obs + (long long)pix * p.ops + n;
-      if (p.out_f32) {
-        float* o = (float*)p.out + ooff;
-        *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
-        *(f32x4*)(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
-      } else {
-        f16x8 h;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) h[e] = (f16)v[e];
-        *(f16x8*)((f16*)p.out + ooff) = h;
-      }
-    }
-  }
+  conv_epilogue<BN, WM, WN, MT, NTL, Cf::NTHREADS>(p, smem, acc, m0, n0, tid_all, is_consumer ? wm : -1, wn, l15, lq);
 }
 
 struct TileCfg {
-  int BM, BN;
-  const void* k1;  // KS == 1
-  const void* k3;  // KS == 3
+  int BM, BN, BK, threads;
+  size_t lds;
+  const void* k1;   // KS == 1 (channel tail masked per lane: any Cin % 8 == 0)
+  const void* k3;   // KS == 3, Cin % BK == 0
+  const void* k3g;  // KS == 3, any Cin % 8 == 0 (per-lane tap decomposition); may be null
   const char* name1;
   const char* name3;
+  const char* name3g;
 };
 
-#define OD_CFG(BM, BN, WM, WN)                                                         \
-  {                                                                                    \
-    BM, BN, (const void*)&od_conv_igemm<BM, BN, WM, WN, 1>,                            \
-        (const void*)&od_conv_igemm<BM, BN, WM, WN, 3>,                                \
-        "od_conv_igemm<" #BM "," #BN "," #WM "," #WN ",1>",                            \
-        "od_conv_igemm<" #BM "," #BN "," #WM "," #WN ",3>"                             \
+#define OD_STR2(x) #x
+#define OD_STR(x) OD_STR2(x)
+#define OD_NAME(BM, BN, BK, ST, WM, WN, KS, MINW, UNI)                                                              \
+  "od_conv_igemm<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", " OD_STR(WM) ", " OD_STR(WN) ", " OD_STR(KS) ", " OD_STR(MINW) ", " #UNI ">"
+#define OD_CFG(BM, BN, BK, ST, WM, WN, MINW)                                                                        \
+  {                                                                                                                 \
+    BM, BN, BK, WM* WN * 64, (size_t)ConvCfg<BM, BN, BK, ST, WM, WN>::LDS_BYTES,                                    \
+        (const void*)&od_conv_igemm<BM, BN, BK, ST, WM, WN, 1, MINW, true, 0>,                                      \
+        (const void*)&od_conv_igemm<BM, BN, BK, ST, WM, WN, 3, MINW, true, 0>, nullptr,                                \
+        OD_NAME(BM, BN, BK, ST, WM, WN, 1, MINW, true), OD_NAME(BM, BN, BK, ST, WM, WN, 3, MINW, true), ""          \
+  }
+#define OD_CFG_S(BM, BN, BK, ST, WM, WN, MINW)                                                                      \
+  {                                                                                                                 \
+    BM, BN, BK, WM* WN * 128, (size_t)ConvCfg<BM, BN, BK, ST, WM, WN, 1>::LDS_BYTES,                                \
+        (const void*)&od_conv_igemm<BM, BN, BK, ST, WM, WN, 1, MINW, true, 1>,                                      \
+        (const void*)&od_conv_igemm<BM, BN, BK, ST, WM, WN, 3, MINW, true, 1>, nullptr,                             \
+        "od_conv_igemm_spec<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", 1>",                    \
+        "od_conv_igemm_spec<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", 3>", ""                 \
+  }
+#define OD_CFG_G(BM, BN, BK, ST, WM, WN, MINW)                                                                      \
+  {                                                                                                                 \
+    BM, BN, BK, WM* WN * 64, (size_t)ConvCfg<BM, BN, BK, ST, WM, WN>::LDS_BYTES,                                    \
+        (const void*)&od_conv_igemm<BM, BN, BK, ST, WM, WN, 1, MINW, true, 0>,                                      \
+        (const void*)&od_conv_igemm<BM, BN, BK, ST, WM, WN, 3, MINW, true, 0>,                                      \
+        (const void*)&od_conv_igemm<BM, BN, BK, ST, WM, WN, 3, MINW, false, 0>,                                        \
+        OD_NAME(BM, BN, BK, ST, WM, WN, 1, MINW, true), OD_NAME(BM, BN, BK, ST, WM, WN, 3, MINW, true),             \
+        OD_NAME(BM, BN, BK, ST, WM, WN, 3, MINW, false)                                                             \
   }
 
+//                   BM   BN  BK ST WM WN minwaves/SIMD
 const TileCfg g_cfgs[] = {
-    OD_CFG(128, 128, 2, 2),
-    OD_CFG(128, 64, 2, 2),
-    OD_CFG(64, 128, 2, 2),
-    OD_CFG(64, 64, 2, 2),
+    OD_CFG_G(128, 128, 64, 2, 2, 2, 2),  // 0: round-1 baseline geometry (64 KiB, 2 WG/CU)
+    OD_CFG_G(128, 64, 64, 2, 2, 2, 2),   // 1
+    OD_CFG_G(64, 128, 64, 2, 2, 2, 2),   // 2
+    OD_CFG_G(64, 64, 64, 2, 2, 2, 2),    // 3
+    OD_CFG(128, 128, 64, 3, 2, 2, 1),    // 4: 96 KiB ring, 1 WG/CU
+    OD_CFG(128, 128, 32, 4, 2, 2, 2),    // 5: 64 KiB ring, 2 WG/CU
+    OD_CFG(128, 128, 32, 3, 2, 2, 2),    // 6: 48 KiB ring, 3 WG/CU
+    OD_CFG(256, 128, 32, 3, 2, 2, 2),    // 7: wave tile 128x64, 72 KiB, 2 WG/CU
+    OD_CFG(256, 128, 64, 3, 4, 2, 2),    // 8: 8 waves, 144 KiB, 1 WG/CU
+    OD_CFG(128, 256, 64, 3, 2, 4, 2),    // 9: 8 waves, 144 KiB
+    OD_CFG(128, 64, 32, 4, 2, 2, 2),     // 10
+    OD_CFG(64, 128, 32, 4, 2, 2, 2),     // 11
+    OD_CFG(64, 64, 32, 4, 2, 2, 2),      // 12
+    OD_CFG_S(128, 128, 64, 2, 2, 2, 4),  // 13: 4 MFMA waves + 4 DMA waves, 64 KiB, 2 WG/CU
+    OD_CFG_S(128, 128, 64, 3, 2, 2, 2),  // 14: same, 3-deep ring (96 KiB, 1 WG/CU)
+    OD_CFG_S(256, 128, 64, 2, 2, 2, 2),  // 15: MFMA wave tile 128x64, 96 KiB, 1 WG/CU
+    OD_CFG_S(256, 128, 64, 3, 2, 2, 2),  // 16: 144 KiB
+    OD_CFG_S(64, 128, 64, 2, 2, 2, 4),   // 17: small-M layers
 };
 constexpr int kNumCfgs = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
-size_t cfg_lds_bytes(const TileCfg& c) {
-  const size_t pipe = 2u * (size_t)(c.BM + c.BN) * ROW_BYTES;
-  const size_t stg = (size_t)c.BM * (c.BN + 4) * sizeof(float);
-  return pipe > stg ? pipe : stg;
-}
-
-int pick_cfg(const od_ctx* ctx, int M, int Cout) {
+// Tile choice from the measured table (profiles/r01/conv_cfg_sweep.txt; MI355X, batch-32 Darknet53 shapes).
+int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize) {
   const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
-  if (Cout <= 64) {
-    return (od_ceil_div(M, 128) >= 2 * cus) ? 1 : 3;
-  }
+  const bool spec_ok = (Cin % 64) == 0;  // wave-specialised kernels are tap-uniform only
+  if (Cout <= 64) return (ksize == 3 && od_ceil_div(M, 128) >= 8 * cus) ? 1 : 3;
   const long t128 = (long)od_ceil_div(M, 128) * od_ceil_div(Cout, 128);
-  if (t128 >= 2L * cus) return 0;
-  const long t64 = (long)od_ceil_div(M, 64) * od_ceil_div(Cout, 128);
-  if (t64 >= 2L * cus) return 2;
-  return 3;
+  if (ksize == 1) {
+    if (!spec_ok) return 3;
+    return M <= 16384 ? 17 : 3;
+  }
+  if (!spec_ok) return t128 >= 2L * cus ? 0 : 2;
+  if (t128 >= cus) return (Cout == 128) ? 2 : 13;  // 4 MFMA waves + 4 DMA waves, 2 workgroups per CU
+  return 14;                                       // few tiles: one deep-ring workgroup per CU
 }
 
 }  // namespace
 
-extern "C" int od_conv_num_tile_cfgs(void) { return kNumCfgs; }
+extern "C" int od_conv_num_tile_cfgs(void) { return kNumCfgs + od_conv_win_num_cfgs(); }
 
 extern "C" int od_conv_weight_dims(int cout, int cin, int ksize, int* cout_pad, int* kpad) {
   OD_REQUIRE(cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), "od_conv_weight_dims: bad dims");
-  if (cout_pad) *cout_pad = od_round_up(cout, 128);
-  if (kpad) *kpad = od_round_up(ksize * ksize * cin, BK);
+  if (cout_pad) *cout_pad = od_round_up(cout, 256);
+  if (kpad) *kpad = od_round_up(ksize * ksize * cin, 64);
   return OD_OK;
 }
 
@@ -308,9 +345,10 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
   const int M = (int)M64;
 
   int cfg = d->tile_cfg;
-  if (cfg < 0) cfg = pick_cfg(ctx, M, d->Cout);
-  OD_REQUIRE(cfg < kNumCfgs, "od_conv2d_fwd: tile_cfg %d out of range", cfg);
-  const TileCfg& tc = g_cfgs[cfg];
+  if (cfg < 0) cfg = pick_cfg(ctx, M, d->Cin, d->Cout, d->ksize);
+  OD_REQUIRE(cfg < kNumCfgs + od_conv_win_num_cfgs(), "od_conv2d_fwd: tile_cfg %d out of range", cfg);
+  const bool use_win = cfg >= kNumCfgs;
+  const TileCfg& tc = g_cfgs[use_win ? 0 : cfg];
 
   ConvKP p;
   p.x = (const f16*)d->x;
@@ -329,32 +367,69 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
   p.stride = d->stride;
   p.pad = pad;
   p.Ktot = d->ksize * d->ksize * d->Cin;
-  p.Kpad = od_round_up(p.Ktot, BK);
+  p.Kstride = od_round_up(p.Ktot, 64);
   p.M = M;
   p.HoWo = Ho * Wo;
   p.act = d->act;
   p.alpha = d->alpha;
   p.res_mode = d->res_mode;
   p.out_f32 = d->out_dtype == OD_DT_F32;
-  p.cin64 = (d->Cin % 64 == 0);
   p.obs = d->out_batch_stride ? d->out_batch_stride : (long long)p.HoWo * d->Cout;
   p.ops = d->out_pix_stride ? d->out_pix_stride : d->Cout;
+  {
+    static int dbg = -1;
+    if (dbg < 0) {
+      const char* e = getenv("OD_CONV_DEBUG");
+      dbg = e ? atoi(e) : 0;
+    }
+    p.dbg = dbg;
+  }
+  if (use_win) {
+    // LDS-window direct 3x3 (conv_win.hip)
+    ConvKernelInfo ki;
+    size_t lds = 0;
+    OD_REQUIRE(d->ksize == 3, "od_conv2d_fwd: tile_cfg %d is a 3x3 window kernel", cfg);
+    if (!od_conv_win_select(cfg - kNumCfgs, p, &ki, &lds)) {
+      od_set_error("od_conv2d_fwd: window kernel cfg %d does not support this shape (stride 1, Cin %% 64 == 0, W = %d)",
+                   cfg, d->W);
+      return OD_ERR_INVALID;
+    }
+    p.mtiles = od_ceil_div(M, ki.BM);
+    p.ntiles = od_ceil_div(d->Cout, ki.BN);
+    if (kernel_name) *kernel_name = ki.name;
+    if (dry_run) return OD_OK;
+    static size_t win_attr[16] = {};
+    const int wi = cfg - kNumCfgs;
+    if (lds > win_attr[wi]) {
+      OD_CHECK_HIP(hipFuncSetAttribute(ki.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      win_attr[wi] = lds;
+    }
+    int np = (ki.BM + 2 * d->W + 2 + 15) / 16;
+    void* wargs[] = {&p, &np};
+    OD_CHECK_HIP(hipLaunchKernel(ki.fn, dim3(p.mtiles * p.ntiles), dim3(ki.threads), wargs, lds, stream));
+    return OD_OK;
+  }
   p.mtiles = od_ceil_div(M, tc.BM);
   p.ntiles = od_ceil_div(d->Cout, tc.BN);
-  // weights/scale/bias are padded to a multiple of 128 output channels, so any BN <= 128 tile stays in bounds.
+  // weights/scale/bias are padded to a multiple of 256 output channels, so any BN <= 256 tile stays in bounds.
 
-  if (kernel_name) *kernel_name = d->ksize == 1 ? tc.name1 : tc.name3;
+  // kernel variant: 1x1 / 3x3-uniform-tap / 3x3-generic (odd channel counts fall back to a config that has one)
+  int variant = d->ksize == 1 ? 0 : ((d->Cin % tc.BK) == 0 ? 1 : 2);
+  if (variant == 2 && !tc.k3g) {
+    od_set_error("od_conv2d_fwd: tile_cfg %d needs Cin %% %d == 0 for 3x3 (Cin = %d); use cfg 0-3", cfg, tc.BK, d->Cin);
+    return OD_ERR_INVALID;
+  }
+  const void* fn = variant == 0 ? tc.k1 : (variant == 1 ? tc.k3 : tc.k3g);
+  if (kernel_name) *kernel_name = variant == 0 ? tc.name1 : (variant == 1 ? tc.name3 : tc.name3g);
   if (dry_run) return OD_OK;
 
-  const void* fn = d->ksize == 1 ? tc.k1 : tc.k3;
-  const size_t lds = cfg_lds_bytes(tc);
-  static bool attr_done[kNumCfgs][2] = {};
-  if (!attr_done[cfg][d->ksize == 3]) {
-    OD_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done[cfg][d->ksize == 3] = true;
+  static bool attr_done[kNumCfgs][3] = {};
+  if (!attr_done[cfg][variant]) {
+    OD_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tc.lds));
+    attr_done[cfg][variant] = true;
   }
   void* args[] = {&p};
-  OD_CHECK_HIP(hipLaunchKernel(fn, dim3(p.mtiles * p.ntiles), dim3(256), args, lds, stream));
+  OD_CHECK_HIP(hipLaunchKernel(fn, dim3(p.mtiles * p.ntiles), dim3(tc.threads), args, tc.lds, stream));
   return OD_OK;
 }
 

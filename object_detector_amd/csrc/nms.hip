@@ -2,10 +2,11 @@
 // predictions, same-class overlaps keep only the most confident).  Integer / bit work, latency-bound; three launches:
 //   sort : one workgroup per image, bitonic sort of the K 64-bit keys in LDS (descending = (conf desc, flat asc)),
 //          gather of the candidates' boxes / classes into rank order
-//   mask : (K/64 x B) workgroups; lane = row i, the wave walks a 64-column word and builds the suppression bitmask
+//   mask : (K/64 x B) workgroups of 16 waves; lane = row i, each wave walks one 64-column word and builds the suppression bitmask
 //          M[i][w] bit j = (j > i && same class && inter > thr * union) -- one u64 per (row, 64-column block)
-//   scan : ONE wavefront per image; the 64x64 diagonal block is resolved with scalar 64-bit ops on SGPRs
-//          (v_readlane), kept rows OR their mask rows into the running `removed` words, 16 rows in flight per lane
+//   scan : the image's mask is staged in LDS (<= 128 KiB), then ONE wavefront runs the greedy scan: each 64x64 diagonal
+//          block is resolved with scalar 64-bit ops on SGPRs (v_readlane; only rows that suppress something take a
+//          step), kept rows OR their mask rows into the running `removed` words, 16 LDS reads in flight per lane
 // The IoU predicate is division-free f32 arithmetic in a fixed order; this TU is compiled with -ffp-contract=off so
 // it is bit-identical to numpy's (oracle/nms.py), which is what makes the kept-index output bit-exact.
 #include "common.h"
@@ -60,7 +61,7 @@ __device__ __forceinline__ bool suppresses(const f32x4 a, float area_a, const f3
   return inter > thr * uni;
 }
 
-__global__ __launch_bounds__(256) void od_nms_mask(const f32x4* __restrict__ sbox, const int* __restrict__ scls,
+__global__ __launch_bounds__(1024) void od_nms_mask(const f32x4* __restrict__ sbox, const int* __restrict__ scls,
                                                    const int* __restrict__ counts, int KP, int W, float thr, int strict,
                                                    u64* __restrict__ mask) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
@@ -69,10 +70,10 @@ __global__ __launch_bounds__(256) void od_nms_mask(const f32x4* __restrict__ sbo
   const int b = blockIdx.y, rb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = counts[b];
   if (rb * 64 >= n) {  // no valid rows here: the scan never reads these words with a live bit, but keep them defined
-    for (int w = rb + wv; w < W; w += 4) mask[((long long)b * KP + rb * 64 + lane) * W + w] = 0ull;
+    for (int w = rb + wv; w < W; w += 16) mask[((long long)b * KP + rb * 64 + lane) * W + w] = 0ull;
     return;
   }
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += 1024) {
     lb[i] = sbox[(long long)b * KP + i];
     lc[i] = scls[(long long)b * KP + i];
   }
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void od_nms_mask(const f32x4* __restrict__ sbo
   const f32x4 a = rowok ? lb[i] : f32x4{0.f, 0.f, 0.f, 0.f};
   const int ca = rowok ? lc[i] : -1;
   const float area_a = (a[2] - a[0]) * (a[3] - a[1]);
-  for (int w = rb + wv; w < W; w += 4) {
+  for (int w = rb + wv; w < W; w += 16) {
     u64 bits = 0ull;
     const int jend = min(64, n - w * 64);
     for (int jj = 0; jj < jend; ++jj) {
@@ -102,49 +103,55 @@ __device__ __forceinline__ u64 readlane64(u64 v, int l) {
   return ((u64)hi << 32) | lo;
 }
 
-__global__ __launch_bounds__(64) void od_nms_scan(const u64* __restrict__ mask, const u64* __restrict__ skeys,
-                                                  const int* __restrict__ counts, int KP, int W, int max_det,
-                                                  int* __restrict__ keep_flat, int* __restrict__ keep_count) {
-  __shared__ u64 keptw[16];
-  const int b = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void od_nms_scan(const u64* __restrict__ mask, const u64* __restrict__ skeys,
+                                                   const int* __restrict__ counts, int KP, int W, int max_det,
+                                                   int* __restrict__ keep_flat, int* __restrict__ keep_count) {
+  extern __shared__ __attribute__((aligned(16))) u64 lm[];  // [n][W] mask rows, then 16 kept words
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int n = __builtin_amdgcn_readfirstlane(counts[b]);
   const u64* mb = mask + (long long)b * KP * W;
-  // diagonal words of every 64-row block, prefetched (static indexing -> registers)
-  u64 diag[16];
-#pragma unroll
-  for (int blk = 0; blk < 16; ++blk) diag[blk] = (blk < W && blk * 64 < n) ? mb[(long long)(blk * 64 + lane) * W + blk] : 0ull;
+  for (int i = tid; i < n * W; i += 256) lm[i] = mb[i];
+  __syncthreads();
+  if (tid >= 64) return;  // the greedy scan itself is one wavefront (no further workgroup barrier below)
+  u64* keptw = lm + (size_t)KP * W;
 
   const int w = lane & 15, g = lane >> 4;
   u64 removed = 0ull;  // lane (g, w): running suppression word w (replicated over g)
-#pragma unroll
-  for (int blk = 0; blk < 16; ++blk) {
+#pragma unroll 1
+  for (int blk = 0; blk < W; ++blk) {
     u64 alive = 0ull;
-    if (blk < W && blk * 64 < n) {
+    if (blk * 64 < n) {
       const int nv = n - blk * 64;
       const u64 valid = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
       alive = ~readlane64(removed, blk) & valid;
-      const u64 dg = diag[blk];
-#pragma unroll
-      for (int r = 0; r < 64; ++r) {
-        const u64 row = readlane64(dg, r);  // SGPR pair
-        if ((alive >> r) & 1ull) alive &= ~row;
+      const u64 dg = (lane < nv) ? lm[(size_t)(blk * 64 + lane) * W + blk] : 0ull;
+      // resolve the 64x64 diagonal block: only rows that suppress something need a step (scalar loop on SGPRs)
+      u64 todo = __ballot(dg != 0ull) & alive;
+      while (todo) {
+        const int r = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        if ((alive >> r) & 1ull) {
+          alive &= ~readlane64(dg, r);
+          todo &= alive;
+        }
       }
-      // kept rows of this block suppress later columns: OR their mask rows (16 independent loads per lane)
+      // kept rows of this block suppress later columns: OR their mask rows (16 LDS reads per lane)
       u64 acc = 0ull;
       const bool wok = w < W && w > blk;
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int r = t * 4 + g;
-        const u64 v = wok ? mb[(long long)(blk * 64 + r) * W + w] : 0ull;
-        acc |= ((alive >> r) & 1ull) ? v : 0ull;
+        const bool on = wok && ((alive >> r) & 1ull);
+        const u64 v = on ? lm[(size_t)(blk * 64 + r) * W + w] : 0ull;
+        acc |= v;
       }
       acc |= __shfl_xor(acc, 16);
       acc |= __shfl_xor(acc, 32);
       removed |= acc;
     }
-    if (lane == 0 && blk < W) keptw[blk] = alive;
+    if (lane == 0) keptw[blk] = alive;
   }
-  __syncthreads();
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): keptw stores landed (single wave, program order)
   int base = 0;
   for (int blk = 0; blk < W; ++blk) {
     const u64 kw = keptw[blk];
@@ -212,10 +219,17 @@ extern "C" int od_nms(od_ctx* ctx, const float* boxes, const uint64_t* keys, con
   hipLaunchKernelGGL(od_nms_sort, dim3(B), dim3(1024), 0, s, boxes, (const u64*)keys, counts, P, NC, K, KP, skeys, sbox,
                      scls);
   OD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(od_nms_mask, dim3(W, B), dim3(256), (size_t)KP * 20, s, sbox, scls, counts, KP, W, iou_threshold,
+  hipLaunchKernelGGL(od_nms_mask, dim3(W, B), dim3(1024), (size_t)KP * 20, s, sbox, scls, counts, KP, W, iou_threshold,
                      strict, mask);
   OD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(od_nms_scan, dim3(B), dim3(64), 0, s, mask, skeys, counts, KP, W, max_det, keep_flat, keep_count);
+  const size_t scan_lds = (size_t)KP * W * 8 + 16 * 8;
+  static size_t scan_attr = 0;
+  if (scan_lds > scan_attr) {
+    OD_CHECK_HIP(hipFuncSetAttribute((const void*)&od_nms_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
+    scan_attr = scan_lds;
+  }
+  hipLaunchKernelGGL(od_nms_scan, dim3(B), dim3(256), scan_lds, s, mask, skeys, counts, KP, W, max_det, keep_flat,
+                     keep_count);
   OD_CHECK_LAUNCH();
   return OD_OK;
 }

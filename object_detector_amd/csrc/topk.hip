@@ -113,14 +113,23 @@ __global__ __launch_bounds__(64) void od_topk_select0(const int* __restrict__ hi
   }
 }
 
+// Block-local compaction: winners / candidates are first collected in LDS (LDS atomics), then the workgroup reserves
+// its output range with ONE global atomic per list -- a global atomic per element serialises on 32 addresses.
 __global__ __launch_bounds__(256) void od_topk_partition(const float* __restrict__ conf, int N, float thr,
                                                          TopkState* __restrict__ st, unsigned long long* __restrict__ keys,
                                                          unsigned* __restrict__ cand, int K, int chunk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned sm_u[];
+  unsigned* l_out = sm_u;           // [chunk] flat indices going straight to the output
+  unsigned* l_cand = sm_u + chunk;  // [chunk] flat indices of the d0 bin
+  __shared__ int n_out, n_cand, base_out, base_cand;
   const int b = blockIdx.y;
   const int d0 = st[b].d0;
   const float* src = conf + (long long)b * N;
-  unsigned long long* ok = keys + (long long)b * K;
-  unsigned* oc = cand + (long long)b * N;
+  if (threadIdx.x == 0) {
+    n_out = 0;
+    n_cand = 0;
+  }
+  __syncthreads();
   const int beg = blockIdx.x * chunk;
   const int end = min(beg + chunk, N);
   for (int i = beg + threadIdx.x; i < end; i += 256) {
@@ -128,13 +137,24 @@ __global__ __launch_bounds__(256) void od_topk_partition(const float* __restrict
     if (!sb) continue;
     const int dg = (int)((sb >> 19) & (NB - 1));
     if (dg > d0) {  // d0 == -1: everything
-      const int slot = atomicAdd(&st[b].nout, 1);
-      ok[slot] = ((unsigned long long)sb << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+      l_out[atomicAdd(&n_out, 1)] = (unsigned)i;
     } else if (dg == d0) {
-      const int slot = atomicAdd(&st[b].ncand, 1);
-      oc[slot] = (unsigned)i;
+      l_cand[atomicAdd(&n_cand, 1)] = (unsigned)i;
     }
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    base_out = n_out ? atomicAdd(&st[b].nout, n_out) : 0;
+    base_cand = n_cand ? atomicAdd(&st[b].ncand, n_cand) : 0;
+  }
+  __syncthreads();
+  unsigned long long* ok = keys + (long long)b * K + base_out;
+  for (int j = threadIdx.x; j < n_out; j += 256) {
+    const unsigned f = l_out[j];
+    ok[j] = ((unsigned long long)__float_as_uint(src[f]) << 32) | (unsigned long long)(0xFFFFFFFFu - f);
+  }
+  unsigned* oc = cand + (long long)b * N + base_cand;
+  for (int j = threadIdx.x; j < n_cand; j += 256) oc[j] = l_cand[j];
 }
 
 // Refine inside the d0 bin.  Remaining key bits, most significant first: score[18:8], score[7:0], ~flat[31:21],
@@ -245,12 +265,13 @@ extern "C" int od_topk_scores(od_ctx* ctx, const float* conf, int B, int N, int 
   // ~8 workgroups per CU in total; chunk is a multiple of 1024 elements so vector loads stay aligned
   int chunks = od_ceil_div(2048, B);
   int chunk = od_round_up(od_ceil_div(N, chunks), 1024);
+  if (chunk > 8192) chunk = 8192;  // partition stages 2 x chunk u32 in LDS (<= 64 KiB)
   chunks = od_ceil_div(N, chunk);
   hipLaunchKernelGGL(od_topk_hist0, dim3(chunks, B), dim3(256), 0, s, conf, N, conf_threshold, hist, chunk);
   OD_CHECK_LAUNCH();
   hipLaunchKernelGGL(od_topk_select0, dim3(B), dim3(64), 0, s, hist, st, K);
   OD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(od_topk_partition, dim3(chunks, B), dim3(256), 0, s, conf, N, conf_threshold, st,
+  hipLaunchKernelGGL(od_topk_partition, dim3(chunks, B), dim3(256), (size_t)chunk * 8, s, conf, N, conf_threshold, st,
                      (unsigned long long*)keys, cand, K, chunk);
   OD_CHECK_LAUNCH();
   hipLaunchKernelGGL(od_topk_refine, dim3(B), dim3(1024), 0, s, conf, N, st, (unsigned long long*)keys, cand, K);

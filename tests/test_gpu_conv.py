@@ -40,6 +40,57 @@ CASES = [
     (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 1),
     (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 2),
     (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 3),
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 4),
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 5),
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 6),
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 7),
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 8),
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 9),
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 10),
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 11),
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 12),
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 13),
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 14),
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 15),
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 16),
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 17),
+    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 4),
+    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 5),
+    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 6),
+    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 7),
+    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 8),
+    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 9),
+    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 10),
+    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 11),
+    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 12),
+    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 13),
+    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 14),
+    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 15),
+    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 16),
+    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 17),
+    (2, 10, 10, 512, 256, 3, 1, "leaky", "same", 13),   # wave-specialised igemm, long K
+    (2, 10, 10, 512, 256, 3, 1, "leaky", "same", 14),   # wave-specialised igemm, long K
+    (2, 10, 10, 512, 256, 3, 1, "leaky", "same", 15),   # wave-specialised igemm, long K
+    (2, 10, 10, 512, 256, 3, 1, "leaky", "same", 16),   # wave-specialised igemm, long K
+    (2, 10, 10, 512, 256, 3, 1, "leaky", "same", 17),   # wave-specialised igemm, long K
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 18),    # LDS-window kernels
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 19),    # LDS-window kernels
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 20),    # LDS-window kernels
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 21),    # LDS-window kernels
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 22),    # LDS-window kernels
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 23),    # LDS-window kernels
+    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 18),      # 4 slices, ragged M (300) and N (320)
+    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 19),      # 4 slices, ragged M (300) and N (320)
+    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 20),      # 4 slices, ragged M (300) and N (320)
+    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 21),      # 4 slices, ragged M (300) and N (320)
+    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 22),      # 4 slices, ragged M (300) and N (320)
+    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 23),      # 4 slices, ragged M (300) and N (320)
+    (1, 40, 40, 128, 256, 3, 1, "leaky", "same", 18),   # W=40: window spans 2W+2 extra pixels
+    (2, 20, 20, 512, 128, 3, 1, "leaky", "up2", 21),    # 8 slices
+    (1, 3, 5, 64, 64, 3, 1, None, "none", 19),          # map smaller than a tile: every edge case at once
+    (2, 16, 16, 32, 64, 3, 2, "leaky", "none", 5),       # Cin=32 is tap-uniform at BK=32
+    (2, 9, 9, 40, 72, 1, 1, "leaky", "none", 5),          # 1x1 channel tail (Cin=40) masked per lane
+    (1, 6, 6, 24, 16, 3, 1, "leaky", "none", 3),          # generic 3x3 (Cin=24) on a legacy config
     (1, 4, 4, 8, 8, 3, 1, None, "none", -1),             # tiny everything: Cin=8, single partial tile
 ]
 

@@ -28,7 +28,7 @@ def test_library_exports_every_header_symbol():
     assert lib2.od_version() >= 100
     a, b = _lib.conv_weight_dims(208, 256, 3)
     assert (a, b) == (256, 2304)
-    assert _lib.conv_weight_dims(64, 32, 3) == (128, 320)  # K tail padded to the 64-deep step
+    assert _lib.conv_weight_dims(64, 32, 3) == (256, 320)  # K tail padded to the 64-deep step
 
 
 def test_missing_library_fails_loudly(tmp_path):
