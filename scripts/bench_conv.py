@@ -65,7 +65,8 @@ def main():
     ]
     big = [("big3x3", 160, 128, 256, 3, 1), ("big1x1", 160, 256, 128, 1, 1)]
     mid = [("mid3x3", 80, 128, 256, 3, 1), ("mid3x3n", 80, 256, 256, 3, 1)]
-    shapes = {"net": net, "big": big, "mid": mid, "all": net + big}[a.shapes]
+    w40 = [("w40k2304", 40, 256, 256, 3, 1)]
+    shapes = {"net": net, "big": big, "mid": mid, "w40": w40, "all": net + big}[a.shapes]
     print(f"{'layer':8s} {'M':>8s} {'N':>5s} {'K':>5s} | " + " | ".join(f"cfg{c:<2d} us    TF/s" for c in cfgs))
     for name, H, Cin, Cout, k, st in shapes:
         row = []

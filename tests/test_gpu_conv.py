@@ -88,6 +88,21 @@ CASES = [
     (1, 40, 40, 128, 256, 3, 1, "leaky", "same", 18),   # W=40: window spans 2W+2 extra pixels
     (2, 20, 20, 512, 128, 3, 1, "leaky", "up2", 21),    # 8 slices
     (1, 3, 5, 64, 64, 3, 1, None, "none", 19),          # map smaller than a tile: every edge case at once
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 24),    # specialised LDS-window kernels
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 25),    # specialised LDS-window kernels
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 26),    # specialised LDS-window kernels
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 27),    # specialised LDS-window kernels
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 28),    # specialised LDS-window kernels
+    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 29),    # specialised LDS-window kernels
+    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 24),      # slice changes (window reload / streaming)
+    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 25),      # slice changes (window reload / streaming)
+    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 26),      # slice changes (window reload / streaming)
+    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 27),      # slice changes (window reload / streaming)
+    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 28),      # slice changes (window reload / streaming)
+    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 29),      # slice changes (window reload / streaming)
+    (1, 40, 40, 128, 256, 3, 1, "leaky", "same", 24),
+    (1, 40, 40, 128, 256, 3, 1, "leaky", "same", 26),
+    (1, 40, 40, 128, 256, 3, 1, "leaky", "same", 28),
     (2, 16, 16, 32, 64, 3, 2, "leaky", "none", 5),       # Cin=32 is tap-uniform at BK=32
     (2, 9, 9, 40, 72, 1, 1, "leaky", "none", 5),          # 1x1 channel tail (Cin=40) masked per lane
     (1, 6, 6, 24, 16, 3, 1, "leaky", "none", 3),          # generic 3x3 (Cin=24) on a legacy config
