@@ -82,6 +82,8 @@ typedef struct od_conv_desc {
   int64_t out_batch_stride;
   int64_t out_pix_stride;
   int32_t tile_cfg; /* -1 = auto; otherwise index into the tile-config table (od_conv_num_tile_cfgs) */
+  int32_t transposed; /* != 0: backward-data of a 3x3 stride-2 conv: x is [B,H,W,Cin] = dZ, out is [B,2H,2W,Cout];
+                         w must be the flipped / channel-swapped pack written by od_pack_weights */
 } od_conv_desc;
 
 int od_conv_weight_dims(int cout, int cin, int ksize, int* cout_pad, int* kpad);
@@ -153,6 +155,43 @@ size_t od_loss_workspace_bytes(int B, int P);
 int od_loss_fwd_bwd(od_ctx* ctx, const float* pred, const float* y, float* grad, float* losses, int B, int P, int NC,
                     float focal_alpha, float focal_gamma, int box_mode, float w_obj, float w_cls, float w_box,
                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K11/K12: training-side kernels (the Keras fit() machinery behind tk.dl.od.ObjectDetector: Conv2D backward,
+ * BatchNormalization in training mode, activation backward, SGD with per-layer LR multipliers -- docs/MODEL.md:19-21,
+ * 84-90).  Activations / gradients f16 NHWC (gradients loss-scaled), statistics and parameters f32.
+ *   backward-data  = od_conv2d_fwd on dZ with the w_bwd pack of od_pack_weights (stride 1), or with
+ *                    od_conv_desc.transposed = 1 (stride 2); the epilogue's residual input accumulates gradients
+ *   backward-weight= od_conv2d_bwd_weight: dw f32 [Cout_pad][Kpad] += dZ^T . shifted(X)   (atomic f32 adds; zero it first)
+ * ---------------------------------------------------------------------------------------------- */
+size_t od_bn_workspace_bytes(long long M, int C);
+/* batch statistics of z [M,C] -> mean, rstd, and the fused (scale, shift) = (gamma*rstd, beta - mean*scale);
+ * run_mean/run_var (may be NULL) updated with `momentum` */
+int od_bn_stats(od_ctx* ctx, const void* z, long long M, int C, const float* gamma, const float* beta, float eps,
+                float* mean, float* rstd, float* scale, float* shift, float* run_mean, float* run_var, float momentum,
+                void* workspace, size_t workspace_bytes, void* stream);
+/* y = act(scale*z + shift) (+ res / up2(res)), f16 */
+int od_scale_act(od_ctx* ctx, const void* z, const float* scale, const float* shift, const void* res, int res_mode,
+                 void* y, int B, int H, int W, int C, int act, float alpha, void* stream);
+/* dz from dy through activation and (bn != 0) BatchNorm; dgamma/dbeta f32 [C] are ACCUMULATED (shared layers);
+ * workspace >= od_bn_workspace_bytes(M,C) + 2*C*4 */
+int od_bn_bwd(od_ctx* ctx, const void* z, const void* dy, const float* scale, const float* shift, const float* mean,
+              const float* rstd, long long M, int C, int act, float alpha, int bn, float* dgamma, float* dbeta,
+              void* dz, void* workspace, size_t workspace_bytes, void* stream);
+int od_conv2d_bwd_weight(od_ctx* ctx, const void* x, const void* dz, float* dw, int B, int H, int W, int Cin, int Cout,
+                         int ksize, int stride, void* stream);
+/* gradient of the nearest-2x upsample add: dup[b,y,x,c] (+)= sum of the 2x2 block of d */
+int od_down2_sum_add(od_ctx* ctx, const void* d, void* dup, int B, int Hh, int Wh, int C, int accumulate, void* stream);
+int od_add_f16(od_ctx* ctx, void* a, const void* b, long long n, void* stream);
+/* loss gradient rows of one pyramid level (f32 [B,P,C]) -> loss-scaled f16 gradient of that level's prediction conv */
+int od_pred_grad_to_level(od_ctx* ctx, const float* grad_pred, void* dz, int B, int P, int C, int row_off, int rows,
+                          float loss_scale, void* stream);
+/* w -= lr*(m = momentum*m + g*inv_loss_scale + weight_decay*w) on a flat f32 segment */
+int od_sgd_step(od_ctx* ctx, float* w, float* m, const float* g, long long n, float lr, float momentum,
+                float weight_decay, float inv_loss_scale, void* stream);
+/* master f32 [Cout][k*k*Cin] -> f16 forward pack [Cout_pad][Kpad] and (w_bwd != NULL) backward-data pack
+ * [Cin_pad][Kpad_t] (taps flipped, channels swapped); both destinations must be pre-zeroed once (padding) */
+int od_pack_weights(od_ctx* ctx, const float* w, void* w_fwd, void* w_bwd, int Cout, int Cin, int ksize, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Native forward plan: the whole layer list of one network executed from C++ (one call per batch, optional

@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
         ("ksize", C.c_int32), ("stride", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float),
         ("res_mode", C.c_int32), ("out_dtype", C.c_int32),
         ("out_batch_stride", C.c_int64), ("out_pix_stride", C.c_int64),
-        ("tile_cfg", C.c_int32),
+        ("tile_cfg", C.c_int32), ("transposed", C.c_int32),
     ]
 
 
@@ -73,6 +73,26 @@ _PROTOS = {
     "od_loss_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                   C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float,
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
+    "od_bn_workspace_bytes": (C.c_size_t, [C.c_longlong, C.c_int]),
+    "od_bn_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                              C.c_void_p, C.c_size_t, C.c_void_p]),
+    "od_scale_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "od_bn_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                            C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                            C.c_void_p, C.c_size_t, C.c_void_p]),
+    "od_conv2d_bwd_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "od_down2_sum_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p]),
+    "od_add_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "od_pred_grad_to_level": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_float, C.c_void_p]),
+    "od_sgd_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_float,
+                              C.c_float, C.c_float, C.c_void_p]),
+    "od_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p]),
     "od_plan_create": (C.c_int, [C.c_void_p, C.POINTER(PlanOp), C.c_int, C.POINTER(C.c_void_p)]),
     "od_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
     "od_plan_capture": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -18,6 +18,7 @@ struct ConvKP {
   int res_mode, out_f32;
   long long obs, ops;
   int mtiles, ntiles;
+  int tconv, Hs, Ws;  // transposed (backward-data of a stride-2 conv): x is [B,Hs,Ws,Cin], gathered through a 2x zero-upsampled view
   int dbg;  // tuning ablations (OD_CONV_DEBUG): bit0 = skip the DMA, bit1 = skip fragment reads + MFMA
 };
 

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), MINW) void od_conv_ig
     lc = lane >> 4;
     piece_off = wave * 16 * ROWB;
   }
-  int a_base[AR], a_hi0[AR], a_wi0[AR];
+  int a_base[AR], a_hi0[AR], a_wi0[AR], a_b[AR];
   unsigned a_vmask[AR];  // UNI: bit t = tap t reads inside the image for this row
 #pragma unroll
   for (int rd = 0; rd < AR; ++rd) {
@@ -104,21 +104,25 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), MINW) void od_conv_ig
       a_hi0[rd] = (int)ho * p.stride - p.pad;
       a_wi0[rd] = (int)wo * p.stride - p.pad;
       a_base[rd] = (((int)b * p.H + a_hi0[rd]) * p.W + a_wi0[rd]) * p.Cin + lc * 8;
+      a_b[rd] = (int)b;
 #pragma unroll
       for (int t = 0; t < KS * KS; ++t) {
         const int hi = a_hi0[rd] + t / KS, wi = a_wi0[rd] + t % KS;
-        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) a_vmask[rd] |= 1u << t;
+        bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        if (p.tconv) ok = ok && !((hi | wi) & 1);  // only the even positions of the zero-upsampled view carry data
+        if (ok) a_vmask[rd] |= 1u << t;
       }
     } else {
       a_hi0[rd] = -(1 << 24);
       a_wi0[rd] = 0;
       a_base[rd] = 0;
+      a_b[rd] = 0;
     }
   }
   const f16* wrow = p.w + (long long)(n0 + rr) * p.Kstride + lc * 8;
 
   // loader state: the NEXT step to stage (steps are staged strictly in order) -- all wave-uniform scalars
-  int ld_k0 = 0, ld_c0 = 0, ld_tap = 0, ld_tapoff = 0, ld_dx = 0;
+  int ld_k0 = 0, ld_c0 = 0, ld_tap = 0, ld_tapoff = 0, ld_dx = 0, ld_dy = 0;
 
   auto stage = [&](int buf) {
     if (p.dbg & 1) return;
@@ -130,7 +134,13 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), MINW) void od_conv_ig
 #pragma unroll
       for (int rd = 0; rd < AR; ++rd) {
         const bool ok = cvalid && ((a_vmask[rd] >> ld_tap) & 1u);
-        const f16* src = ok ? p.x + (a_base[rd] + koff) : p.zero;
+        const f16* src;
+        if (KS == 3 && p.tconv) {
+          const int u = (a_hi0[rd] + ld_dy) >> 1, v = (a_wi0[rd] + ld_dx) >> 1;
+          src = ok ? p.x + (((a_b[rd] * p.Hs + u) * p.Ws + v) * p.Cin + lc * 8 + ld_c0) : p.zero;
+        } else {
+          src = ok ? p.x + (a_base[rd] + koff) : p.zero;
+        }
         glds16(src, abuf + rd * RPR * ROWB);
       }
     } else {
@@ -159,6 +169,7 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), MINW) void od_conv_ig
         ++ld_tap;
         if (++ld_dx == 3) {
           ld_dx = 0;
+          ++ld_dy;
           ld_tapoff += (p.W - 2) * p.Cin;
         } else {
           ld_tapoff += p.Cin;
@@ -335,8 +346,14 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
   OD_REQUIRE(d->res_mode == OD_RES_NONE || d->res, "od_conv2d_fwd: res_mode set but res is null");
   OD_REQUIRE(d->act >= OD_ACT_LINEAR && d->act <= OD_ACT_ELU, "od_conv2d_fwd: bad act");
   const int pad = d->ksize / 2;
-  const int Ho = (d->H + 2 * pad - d->ksize) / d->stride + 1;
-  const int Wo = (d->W + 2 * pad - d->ksize) / d->stride + 1;
+  const bool tconv = d->transposed != 0;
+  if (tconv)
+    OD_REQUIRE(d->ksize == 3 && d->stride == 2 && d->Cin % 64 == 0,
+               "od_conv2d_fwd: transposed mode is the backward-data of a 3x3 stride-2 conv (Cin %% 64 == 0)");
+  // transposed: a stride-1 conv over the 2x zero-upsampled [B, 2H, 2W, Cin] view of x
+  const int Hv = tconv ? 2 * d->H : d->H, Wv = tconv ? 2 * d->W : d->W, stride = tconv ? 1 : d->stride;
+  const int Ho = (Hv + 2 * pad - d->ksize) / stride + 1;
+  const int Wo = (Wv + 2 * pad - d->ksize) / stride + 1;
   if (d->res_mode == OD_RES_UP2)
     OD_REQUIRE(Ho % 2 == 0 && Wo % 2 == 0, "od_conv2d_fwd: OD_RES_UP2 needs even output size");
   const long long M64 = (long long)d->B * Ho * Wo;
@@ -358,13 +375,16 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
   p.res = (const f16*)d->res;
   p.out = d->out;
   p.zero = (const f16*)ctx->zero_page;
-  p.H = d->H;
-  p.W = d->W;
+  p.H = Hv;
+  p.W = Wv;
+  p.tconv = tconv;
+  p.Hs = d->H;
+  p.Ws = d->W;
   p.Cin = d->Cin;
   p.Ho = Ho;
   p.Wo = Wo;
   p.Cout = d->Cout;
-  p.stride = d->stride;
+  p.stride = stride;
   p.pad = pad;
   p.Ktot = d->ksize * d->ksize * d->Cin;
   p.Kstride = od_round_up(p.Ktot, 64);

@@ -1,0 +1,207 @@
+// K11 (backward-weight): dW[co][tap*Cin + ci] += sum_m dZ[m][co] * X[shift_tap(m)][ci]   (3x3 / 1x1, stride 1 / 2)
+//
+// GEMM with the PIXEL index as the reduction dimension: out tile = 128 output channels x 128 (tap, ci) columns, each
+// workgroup reduces a contiguous slice of the M = B*Ho*Wo pixels (split-K over workgroups) and adds its f32 partial tile
+// into dW with global_atomic_add_f32.  Both operands live pixel-major in HBM (NHWC), i.e. k-MINOR for this GEMM, so the
+// 32-pixel x 128-channel LDS tiles are read with ds_read_b64_tr_b16 (the CDNA4 transposing LDS read) to form
+// v_mfma_f32_16x16x32_f16 fragments: lane (l15, lq) gets channel l15 of pixels 8*lq .. 8*lq+7 from two 4x16 blocks.
+// Tiles arrive by LDS-DMA (global_load_lds_dwordx4, per-lane source = the tap-shifted input pixel or the zero page);
+// 256-B rows with the 16-B chunk index XORed by ((r&3) | ((r>>3)&1)<<2) << 1 make the transposed reads conflict-free.
+//
+// Replaces the weight-gradient half of the Keras Conv2D backward pass of the reference's (unseen) training loop
+// (SURVEY.md §2.2 K11); results are f32 (loss-scaled), consumed by od_sgd_step.
+#include "conv_common.h"
+
+namespace {
+
+typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+struct WgradKP {
+  const f16* x;    // [B,H,W,Cin]
+  const f16* dz;   // [B,Ho,Wo,Cout]
+  float* dw;       // [Cout_pad][Kstride] f32
+  const f16* zero;
+  int H, W, Cin, Ho, Wo, Cout, ks, stride, pad;
+  int Kstride, Ktot, M, HoWo;
+  int rtiles, ctiles, split, chunks_per_split;
+};
+
+constexpr int KC = 32;          // pixels per K chunk (one MFMA k step)
+constexpr int TILE = 128;       // out tile edge
+constexpr int ROWB = 256;       // LDS row bytes (128 f16)
+constexpr int OPER_BYTES = KC * ROWB;  // 8 KiB per operand per stage
+
+__device__ __forceinline__ int swz_key(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }
+
+__global__ __launch_bounds__(256, 2) void od_conv_wgrad(WgradKP p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * OPER_BYTES];  // [stage][D | X]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  int bid = blockIdx.x;
+  const int sp = bid % p.split;
+  bid /= p.split;
+  const int ct = bid % p.ctiles, rt = bid / p.ctiles;
+  const int co0 = rt * TILE, n0 = ct * TILE;
+  const int chunk0 = sp * p.chunks_per_split;
+  const int nchunks_total = (p.M + KC - 1) / KC;
+  const int nch = min(p.chunks_per_split, nchunks_total - chunk0);
+  if (nch <= 0) return;
+
+  // ---- DMA mapping: instruction q (1 KiB) = tile rows 4q .. 4q+3; lane = (row 4q + lane/16, physical chunk lane%16)
+  // wave w issues q = w and q = w + 4 for both operands
+  const int prow[2] = {4 * wave + (lane >> 4), 4 * (wave + 4) + (lane >> 4)};
+  int lchunk[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) lchunk[h] = (lane & 15) ^ swz_key(prow[h]);
+  // X operand: this lane's columns (same for both rows when the keys agree; computed per row)
+  int xtap_dy[2], xtap_dx[2], xci[2];
+  bool xcol_ok[2], dcol_ok[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int j = n0 + lchunk[h] * 8;
+    const int tap = j / p.Cin;
+    xci[h] = j - tap * p.Cin;
+    xtap_dy[h] = tap / p.ks;
+    xtap_dx[h] = tap - xtap_dy[h] * p.ks;
+    xcol_ok[h] = j < p.Ktot;
+    dcol_ok[h] = (co0 + lchunk[h] * 8) < p.Cout;
+  }
+
+  auto stage = [&](int chunk, int buf) {
+    char* dbuf = smem + buf * 2 * OPER_BYTES;
+    char* xbuf = dbuf + OPER_BYTES;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = wave + 4 * h;
+      const int m = (chunk0 + chunk) * KC + prow[h];
+      const bool mok = m < p.M;
+      const unsigned b = (unsigned)m / (unsigned)p.HoWo;
+      const unsigned pix = (unsigned)m - b * (unsigned)p.HoWo;
+      const unsigned ho = pix / (unsigned)p.Wo, wo = pix - ho * (unsigned)p.Wo;
+      const f16* dsrc = (mok && dcol_ok[h]) ? p.dz + ((long long)m * p.Cout + co0 + lchunk[h] * 8) : p.zero;
+      glds16(dsrc, dbuf + q * 1024);
+      const int hi = (int)ho * p.stride + xtap_dy[h] - p.pad, wi = (int)wo * p.stride + xtap_dx[h] - p.pad;
+      const bool xok = mok && xcol_ok[h] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      const f16* xsrc = xok ? p.x + ((((long long)b * p.H + hi) * p.W + wi) * p.Cin + xci[h]) : p.zero;
+      glds16(xsrc, xbuf + q * 1024);
+    }
+  };
+
+  // ---- MFMA side: wave (wr, wc) owns a 64 x 64 sub-tile ---------------------------------------------------------
+  const int wr = wave >> 1, wc = wave & 1;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // transposed-read addressing: lane 4q+p of a 16-lane group supplies row q, 4 columns starting at 4p
+  const int tq = l15 >> 2, tp = l15 & 3;
+  int roff[2];  // byte offset of (row, swizzle) for the two 4-row blocks of this lane's 8 pixels
+  int rkey[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = 8 * lq + 4 * h + tq;
+    roff[h] = r * ROWB;
+    rkey[h] = swz_key(r);
+  }
+
+  stage(0, 0);
+  __syncthreads();  // vmcnt(0): chunk 0 landed
+  for (int c = 0; c < nch; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nch) stage(c + 1, buf ^ 1);
+    const char* dbuf = smem + buf * 2 * OPER_BYTES;
+    const char* xbuf = dbuf + OPER_BYTES;
+    f16x8 af[4], bf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = (wr * 64 + i * 16) / 4 + tp;  // 8-byte unit inside the row (16 channels = 4 units)
+      h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+          (__attribute__((address_space(3))) h4*)(dbuf + roff[0] + (((u >> 1) ^ rkey[0]) * 16) + (u & 1) * 8));
+      h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+          (__attribute__((address_space(3))) h4*)(dbuf + roff[1] + (((u >> 1) ^ rkey[1]) * 16) + (u & 1) * 8));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        af[i][e] = (f16)lo[e];
+        af[i][4 + e] = (f16)hi[e];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int u = (wc * 64 + j * 16) / 4 + tp;
+      h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+          (__attribute__((address_space(3))) h4*)(xbuf + roff[0] + (((u >> 1) ^ rkey[0]) * 16) + (u & 1) * 8));
+      h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+          (__attribute__((address_space(3))) h4*)(xbuf + roff[1] + (((u >> 1) ^ rkey[1]) * 16) + (u & 1) * 8));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bf[j][e] = (f16)lo[e];
+        bf[j][4 + e] = (f16)hi[e];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    __syncthreads();
+  }
+
+  // ---- f32 partial tile -> dW (atomic adds; 16 lanes = 64 contiguous bytes per row) ---------------------------
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wc * 64 + j * 16 + l15;
+      if (col < p.Ktot) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = co0 + wr * 64 + i * 16 + lq * 4 + e;
+          if (co < p.Cout) atomicAdd(p.dw + (long long)co * p.Kstride + col, acc[i][j][e]);
+        }
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" int od_conv2d_bwd_weight(od_ctx* ctx, const void* x, const void* dz, float* dw, int B, int H, int W, int Cin,
+                                    int Cout, int ksize, int stride, void* stream) {
+  OD_REQUIRE(ctx && x && dz && dw, "od_conv2d_bwd_weight: null argument");
+  OD_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "od_conv2d_bwd_weight: bad ksize/stride");
+  OD_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0,
+             "od_conv2d_bwd_weight: Cin/Cout must be multiples of 8");
+  WgradKP p;
+  p.x = (const f16*)x;
+  p.dz = (const f16*)dz;
+  p.dw = dw;
+  p.zero = (const f16*)ctx->zero_page;
+  p.H = H;
+  p.W = W;
+  p.Cin = Cin;
+  p.ks = ksize;
+  p.stride = stride;
+  p.pad = ksize / 2;
+  p.Ho = (H + 2 * p.pad - ksize) / stride + 1;
+  p.Wo = (W + 2 * p.pad - ksize) / stride + 1;
+  p.Cout = Cout;
+  p.Ktot = ksize * ksize * Cin;
+  p.Kstride = od_round_up(p.Ktot, 64);
+  const long long M64 = (long long)B * p.Ho * p.Wo;
+  OD_REQUIRE(M64 * Cout < (1LL << 31) && (long long)B * H * W * Cin < (1LL << 31), "od_conv2d_bwd_weight: too large");
+  p.M = (int)M64;
+  p.HoWo = p.Ho * p.Wo;
+  p.rtiles = od_ceil_div(Cout, TILE);
+  p.ctiles = od_ceil_div(p.Ktot, TILE);
+  const int nchunks = od_ceil_div(p.M, KC);
+  const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
+  int split = od_ceil_div(4 * cus, p.rtiles * p.ctiles);
+  if (split > nchunks) split = nchunks;
+  if (split < 1) split = 1;
+  p.chunks_per_split = od_ceil_div(nchunks, split);
+  p.split = od_ceil_div(nchunks, p.chunks_per_split);
+  hipLaunchKernelGGL(od_conv_wgrad, dim3(p.rtiles * p.ctiles * p.split), dim3(256), 0, (hipStream_t)stream, p);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}

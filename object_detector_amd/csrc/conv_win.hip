@@ -443,7 +443,7 @@ int od_conv_win_num_cfgs() { return kNumWin; }
 
 bool od_conv_win_select(int idx, const ConvKP& p, ConvKernelInfo* info, size_t* lds_bytes) {
   if (idx < 0 || idx >= kNumWin) return false;
-  if (p.stride != 1 || p.pad != 1 || (p.Cin & 63) != 0 || p.Ho != p.H || p.Wo != p.W) return false;
+  if (p.stride != 1 || p.pad != 1 || (p.Cin & 63) != 0 || p.Ho != p.H || p.Wo != p.W || p.tconv) return false;
   const WinEntry& e = g_win[idx];
   const int np = (e.BM + 2 * p.W + 2 + 15) / 16;
   if (np * 2 > e.max_win_instr) return false;  // window cannot be streamed in 8 steps

@@ -1,0 +1,416 @@
+// K11 (elementwise part) + K12: training-side kernels around the MFMA convolutions.  All HBM-bound; NHWC f16
+// activations / gradients, f32 statistics and parameters.  Reductions are deterministic (per-workgroup partials summed
+// in a fixed order), so a training step is bit-reproducible on one GPU.
+//
+//   od_bn_stats        per-channel mean / rstd of z = conv(x) over (B,H,W) (BatchNorm in training mode), folded into the
+//                      (scale, shift) pair of the fused form  y = act(scale*z + shift) (+ residual)
+//   od_scale_act       that fused elementwise form (the inference conv epilogue, as its own pass)
+//   od_bn_bwd          da = dy * act'(.) ; dgamma = sum(da*xhat), dbeta = sum(da) ; dz = gamma*rstd*(da - dbeta/N - xhat*dgamma/N)
+//   od_down2_sum_add   gradient of the nearest 2x upsample in the FPN top-down add
+//   od_sgd_step        SGD + momentum + weight decay on f32 masters with per-layer LR multipliers
+//                      (docs/MODEL.md:84-90: shared layers x 1/share-count, base network x 1/100), re-packs the f16 copies
+//
+// reference: the Keras BatchNormalization / activation / optimizer machinery behind the (unseen) `fit` of
+// tk.dl.od.ObjectDetector; specified here by docs/MODEL.md:19-21,84-90.
+#include "common.h"
+
+namespace {
+
+constexpr int RED_ROWS = 512;  // rows per workgroup in the channel reductions
+
+__device__ __forceinline__ float act_fwd(float a, int act, float alpha) {
+  if (act == OD_ACT_LEAKY) return a > 0.f ? a : a * alpha;
+  if (act == OD_ACT_ELU) return a > 0.f ? a : alpha * expm1f(a);
+  return a;
+}
+__device__ __forceinline__ float act_grad(float a, int act, float alpha) {
+  if (act == OD_ACT_LEAKY) return a > 0.f ? 1.f : alpha;
+  if (act == OD_ACT_ELU) return a > 0.f ? 1.f : alpha * expf(a);
+  return 1.f;
+}
+
+// ---- channel reductions: thread = (8-channel group, row lane); LDS tree over row lanes; one partial row per workgroup
+// MODE 0: (sum z, sum z^2)   MODE 1: (sum da, sum da*xhat)
+template <int MODE>
+__global__ __launch_bounds__(256) void od_chan_reduce(const f16* __restrict__ z, const f16* __restrict__ dy,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      long long M, int C, int act, float alpha,
+                                                      float* __restrict__ partials) {
+  extern __shared__ float red[];  // [2][256][8]
+  const int G = C >> 3;                       // channel groups
+  const int tid = threadIdx.x;
+  const int lanes = 256 / min(G, 256);        // row lanes per group inside one pass
+  const long long r0 = (long long)blockIdx.x * RED_ROWS;
+  const long long r1 = min(r0 + RED_ROWS, M);
+  for (int g0 = 0; g0 < G; g0 += 256) {       // C > 2048 loops (not used by this network)
+    const int g = g0 + (lanes > 1 ? tid % G : tid);
+    const int rl = lanes > 1 ? tid / G : 0;
+    float s0[8], s1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+    if (g < G && rl < lanes) {
+      float sc[8], sh[8], mu[8], rs[8];
+      if (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          sc[e] = scale[g * 8 + e];
+          sh[e] = shift[g * 8 + e];
+          mu[e] = mean[g * 8 + e];
+          rs[e] = rstd[g * 8 + e];
+        }
+      }
+      for (long long r = r0 + rl; r < r1; r += lanes) {
+        const f16x8 zv = *(const f16x8*)(z + r * C + g * 8);
+        if (MODE == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = (float)zv[e];
+            s0[e] += v;
+            s1[e] += v * v;
+          }
+        } else {
+          const f16x8 dv = *(const f16x8*)(dy + r * C + g * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float zf = (float)zv[e];
+            const float da = (float)dv[e] * act_grad(zf * sc[e] + sh[e], act, alpha);
+            s0[e] += da;
+            s1[e] += da * ((zf - mu[e]) * rs[e]);
+          }
+        }
+      }
+    }
+    float* r0p = red + tid * 8;
+    float* r1p = red + 256 * 8 + tid * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      r0p[e] = s0[e];
+      r1p[e] = s1[e];
+    }
+    __syncthreads();
+    // fixed-order sum over the row lanes of each group
+    if (g < G && rl == 0) {
+      for (int l = 1; l < lanes; ++l) {
+        const float* a = red + (l * G + (tid % G)) * 8;
+        const float* b = a + 256 * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s0[e] += a[e];
+          s1[e] += b[e];
+        }
+      }
+      float* out = partials + (long long)blockIdx.x * 2 * C;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        out[g * 8 + e] = s0[e];
+        out[C + g * 8 + e] = s1[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// fixed-order final sums; MODE 0 -> mean, rstd, scale, shift (and running stats); MODE 1 -> dgamma, dbeta
+template <int MODE>
+__global__ __launch_bounds__(256) void od_chan_final(const float* __restrict__ partials, int nblocks, int C, float invM,
+                                                     float eps, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ o0,
+                                                     float* __restrict__ o1, float* __restrict__ o2,
+                                                     float* __restrict__ o3, float* __restrict__ run_mean,
+                                                     float* __restrict__ run_var, float momentum) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int i = 0; i < nblocks; ++i) {
+    a += partials[(long long)i * 2 * C + c];
+    b += partials[(long long)i * 2 * C + C + c];
+  }
+  if (MODE == 0) {
+    const float mu = a * invM;
+    const float var = fmaxf(b * invM - mu * mu, 0.f);
+    const float rs = rsqrtf(var + eps);
+    const float sc = gamma[c] * rs;
+    o0[c] = mu;
+    o1[c] = rs;
+    o2[c] = sc;
+    o3[c] = beta[c] - mu * sc;
+    if (run_mean) {
+      run_mean[c] = momentum * run_mean[c] + (1.f - momentum) * mu;
+      run_var[c] = momentum * run_var[c] + (1.f - momentum) * var;
+    }
+  } else {
+    o0[c] += b;  // dgamma (accumulates: the prediction module is shared by three levels)
+    o1[c] += a;  // dbeta
+    o2[c] = b;   // this call's sums, consumed by the apply pass
+    o3[c] = a;
+  }
+}
+
+__global__ __launch_bounds__(256) void od_scale_act_k(const f16* __restrict__ z, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, const f16* __restrict__ res,
+                                                      f16* __restrict__ y, long long nvec, int C8, int act, float alpha,
+                                                      int res_up2, int H, int W) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+    const int g = (int)(i % C8);
+    const f16x8 zv = *(const f16x8*)(z + i * 8);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = act_fwd((float)zv[e] * scale[g * 8 + e] + shift[g * 8 + e], act, alpha);
+    if (res) {
+      long long ri = i;
+      if (res_up2) {
+        long long pix = i / C8;
+        const int x = (int)(pix % W);
+        pix /= W;
+        const int yy = (int)(pix % H);
+        const long long b = pix / H;
+        ri = ((b * (H >> 1) + (yy >> 1)) * (W >> 1) + (x >> 1)) * C8 + g;
+      }
+      const f16x8 rv = *(const f16x8*)(res + ri * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+    }
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+    *(f16x8*)(y + i * 8) = o;
+  }
+}
+
+// dz = gamma*rstd*(da - dbeta/N - xhat*dgamma/N), da = dy*act'(scale*z+shift); bn == 0: dz = da (conv bias layer)
+__global__ __launch_bounds__(256) void od_bn_bwd_apply_k(const f16* __restrict__ z, const f16* __restrict__ dy,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ sum_dax, const float* __restrict__ sum_da,
+                                                         f16* __restrict__ dz, long long nvec, int C8, float invM, int act,
+                                                         float alpha, int bn) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+    const int g = (int)(i % C8);
+    const f16x8 zv = *(const f16x8*)(z + i * 8);
+    const f16x8 dv = *(const f16x8*)(dy + i * 8);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = g * 8 + e;
+      const float zf = (float)zv[e];
+      const float da = (float)dv[e] * act_grad(zf * scale[c] + shift[c], act, alpha);
+      float r = da;
+      if (bn) {
+        const float xh = (zf - mean[c]) * rstd[c];
+        r = scale[c] * (da - sum_da[c] * invM - xh * sum_dax[c] * invM);  // scale = gamma*rstd
+      }
+      o[e] = (f16)r;
+    }
+    *(f16x8*)(dz + i * 8) = o;
+  }
+}
+
+// d_up[b,y,x,c] (+)= sum over the 2x2 block of d[b,2y..,2x..,c]
+__global__ __launch_bounds__(256) void od_down2_sum_add_k(const f16* __restrict__ d, f16* __restrict__ dup, long long nvec,
+                                                          int Hh, int Wh, int C8, int accumulate) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+    const int g = (int)(i % C8);
+    long long pix = i / C8;
+    const int x = (int)(pix % Wh);
+    pix /= Wh;
+    const int y = (int)(pix % Hh);
+    const long long b = pix / Hh;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (accumulate) {
+      const f16x8 a = *(const f16x8*)(dup + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long long si = ((b * (2 * Hh) + 2 * y + (q >> 1)) * (2 * Wh) + 2 * x + (q & 1)) * C8 + g;
+      const f16x8 a = *(const f16x8*)(d + si * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += (float)a[e];
+    }
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+    *(f16x8*)(dup + i * 8) = o;
+  }
+}
+
+// f16 NHWC elementwise add: a += b
+__global__ __launch_bounds__(256) void od_add_f16_k(f16* __restrict__ a, const f16* __restrict__ b, long long nvec) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+    const f16x8 x = *(const f16x8*)(a + i * 8), y = *(const f16x8*)(b + i * 8);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)((float)x[e] + (float)y[e]);
+    *(f16x8*)(a + i * 8) = o;
+  }
+}
+
+// SGD + momentum on a flat f32 segment; optional f16 re-pack of conv weights into the forward layout [Cout_pad][Kpad]
+// and the backward-data layout [Cin_pad][Kpad_t] (taps flipped, in/out channels swapped)
+__global__ __launch_bounds__(256) void od_sgd_k(float* __restrict__ w, float* __restrict__ m, const float* __restrict__ g,
+                                                long long n, float lr, float momentum, float wd, float inv_scale) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float grad = g[i] * inv_scale + wd * w[i];
+    const float mv = momentum * m[i] + grad;
+    m[i] = mv;
+    w[i] -= lr * mv;
+  }
+}
+
+// master weights f32 [Cout][k*k*Cin] (k index = tap*Cin + cin) -> forward f16 [Cout_pad][Kpad] and, for the backward-data
+// conv, f16 [Cin_pad][Kpad_t] with wt[ci][(k*k-1-tap)*Cout + co] = w[co][tap*Cin + ci]
+__global__ __launch_bounds__(256) void od_pack_w_k(const float* __restrict__ w, f16* __restrict__ wf, f16* __restrict__ wt,
+                                                   int Cout, int Cin, int taps, int Kpad, int Kpad_t) {
+  const long long n = (long long)Cout * taps * Cin;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int ci = (int)(i % Cin);
+    const long long r = i / Cin;
+    const int tap = (int)(r % taps);
+    const int co = (int)(r / taps);
+    const f16 v = (f16)w[i];
+    wf[(long long)co * Kpad + tap * Cin + ci] = v;
+    if (wt) wt[(long long)ci * Kpad_t + (taps - 1 - tap) * Cout + co] = v;
+  }
+}
+
+// loss gradient w.r.t. pred (f32 [B,P,C], rows of one pyramid level) -> loss-scaled f16 NHWC gradient of that level's
+// prediction conv output [B, rows*C] (rows = H*W*8 priors, C = 2+NC+4 -> H*W x 8*C channels)
+__global__ __launch_bounds__(256) void od_pred_grad_level_k(const float* __restrict__ g, f16* __restrict__ dz, int B,
+                                                            long long img_stride, long long off, long long n_per_img,
+                                                            float scale) {
+  const long long total = (long long)B * n_per_img;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long b = i / n_per_img, r = i - b * n_per_img;
+    dz[i] = (f16)(g[b * img_stride + off + r] * scale);
+  }
+}
+
+unsigned grid_for(long long nvec) {
+  long long b = (nvec + 255) / 256;
+  return (unsigned)(b > 256 * 16 ? 256 * 16 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" size_t od_bn_workspace_bytes(long long M, int C) {
+  if (M <= 0 || C <= 0) return 0;
+  return (size_t)((M + RED_ROWS - 1) / RED_ROWS) * 2 * C * sizeof(float);
+}
+
+extern "C" int od_bn_stats(od_ctx* ctx, const void* z, long long M, int C, const float* gamma, const float* beta,
+                           float eps, float* mean, float* rstd, float* scale, float* shift, float* run_mean,
+                           float* run_var, float momentum, void* workspace, size_t workspace_bytes, void* stream) {
+  OD_REQUIRE(ctx && z && gamma && beta && mean && rstd && scale && shift && workspace, "od_bn_stats: null argument");
+  OD_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "od_bn_stats: C must be a multiple of 8, <= 2048");
+  const int nblocks = (int)((M + RED_ROWS - 1) / RED_ROWS);
+  if (workspace_bytes < od_bn_workspace_bytes(M, C)) {
+    od_set_error("od_bn_stats: workspace too small");
+    return OD_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  hipLaunchKernelGGL(od_chan_reduce<0>, dim3(nblocks), dim3(256), 2 * 256 * 8 * sizeof(float), s, (const f16*)z,
+                     (const f16*)nullptr, nullptr, nullptr, nullptr, nullptr, M, C, 0, 0.f, part);
+  OD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(od_chan_final<0>, dim3(od_ceil_div(C, 256)), dim3(256), 0, s, part, nblocks, C, 1.f / (float)M, eps,
+                     gamma, beta, mean, rstd, scale, shift, run_mean, run_var, momentum);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
+extern "C" int od_scale_act(od_ctx* ctx, const void* z, const float* scale, const float* shift, const void* res,
+                            int res_mode, void* y, int B, int H, int W, int C, int act, float alpha, void* stream) {
+  OD_REQUIRE(ctx && z && scale && shift && y, "od_scale_act: null argument");
+  OD_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "od_scale_act: bad dims");
+  OD_REQUIRE(res_mode == OD_RES_NONE || res, "od_scale_act: res_mode set but res is null");
+  const long long nvec = (long long)B * H * W * (C / 8);
+  hipLaunchKernelGGL(od_scale_act_k, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const f16*)z, scale, shift,
+                     res_mode == OD_RES_NONE ? (const f16*)nullptr : (const f16*)res, (f16*)y, nvec, C / 8, act, alpha,
+                     res_mode == OD_RES_UP2, H, W);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
+extern "C" int od_bn_bwd(od_ctx* ctx, const void* z, const void* dy, const float* scale, const float* shift,
+                         const float* mean, const float* rstd, long long M, int C, int act, float alpha, int bn,
+                         float* dgamma, float* dbeta, void* dz, void* workspace, size_t workspace_bytes, void* stream) {
+  OD_REQUIRE(ctx && z && dy && scale && shift && dz && dgamma && dbeta && workspace, "od_bn_bwd: null argument");
+  OD_REQUIRE(!bn || (mean && rstd), "od_bn_bwd: bn needs mean/rstd");
+  OD_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "od_bn_bwd: C must be a multiple of 8, <= 2048");
+  const int nblocks = (int)((M + RED_ROWS - 1) / RED_ROWS);
+  const size_t need = od_bn_workspace_bytes(M, C) + 2 * (size_t)C * sizeof(float);
+  if (workspace_bytes < need) {
+    od_set_error("od_bn_bwd: workspace %zu < %zu", workspace_bytes, need);
+    return OD_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  float* sums = part + (size_t)nblocks * 2 * C;  // [2][C]: this call's sum(da*xhat), sum(da)
+  // without BN the "mean/rstd" are not used by the sums we need (dbeta only); pass scale/shift twice to keep pointers valid
+  hipLaunchKernelGGL(od_chan_reduce<1>, dim3(nblocks), dim3(256), 2 * 256 * 8 * sizeof(float), s, (const f16*)z,
+                     (const f16*)dy, scale, shift, bn ? mean : shift, bn ? rstd : scale, M, C, act, alpha, part);
+  OD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(od_chan_final<1>, dim3(od_ceil_div(C, 256)), dim3(256), 0, s, part, nblocks, C, 0.f, 0.f,
+                     (const float*)nullptr, (const float*)nullptr, dgamma, dbeta, sums, sums + C, (float*)nullptr,
+                     (float*)nullptr, 0.f);
+  OD_CHECK_LAUNCH();
+  const long long nvec = M * (C / 8);
+  hipLaunchKernelGGL(od_bn_bwd_apply_k, dim3(grid_for(nvec)), dim3(256), 0, s, (const f16*)z, (const f16*)dy, scale,
+                     shift, bn ? mean : shift, bn ? rstd : scale, sums, sums + C, (f16*)dz, nvec, C / 8, 1.f / (float)M,
+                     act, alpha, bn);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
+extern "C" int od_down2_sum_add(od_ctx* ctx, const void* d, void* dup, int B, int Hh, int Wh, int C, int accumulate,
+                                void* stream) {
+  OD_REQUIRE(ctx && d && dup && B > 0 && Hh > 0 && Wh > 0 && C > 0 && C % 8 == 0, "od_down2_sum_add: bad argument");
+  const long long nvec = (long long)B * Hh * Wh * (C / 8);
+  hipLaunchKernelGGL(od_down2_sum_add_k, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const f16*)d, (f16*)dup,
+                     nvec, Hh, Wh, C / 8, accumulate);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
+extern "C" int od_add_f16(od_ctx* ctx, void* a, const void* b, long long n, void* stream) {
+  OD_REQUIRE(ctx && a && b && n > 0 && n % 8 == 0, "od_add_f16: n must be a positive multiple of 8");
+  hipLaunchKernelGGL(od_add_f16_k, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (f16*)a, (const f16*)b, n / 8);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
+extern "C" int od_sgd_step(od_ctx* ctx, float* w, float* m, const float* g, long long n, float lr, float momentum,
+                           float weight_decay, float inv_loss_scale, void* stream) {
+  OD_REQUIRE(ctx && w && m && g && n > 0, "od_sgd_step: bad argument");
+  hipLaunchKernelGGL(od_sgd_k, dim3(grid_for((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, w, m, g, n, lr, momentum,
+                     weight_decay, inv_loss_scale);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
+extern "C" int od_pack_weights(od_ctx* ctx, const float* w, void* w_fwd, void* w_bwd, int Cout, int Cin, int ksize,
+                               void* stream) {
+  OD_REQUIRE(ctx && w && w_fwd && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3), "od_pack_weights: bad argument");
+  const int taps = ksize * ksize;
+  const int Kpad = od_round_up(taps * Cin, 64), Kpad_t = od_round_up(taps * Cout, 64);
+  const long long n = (long long)Cout * taps * Cin;
+  hipLaunchKernelGGL(od_pack_w_k, dim3(grid_for((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, w, (f16*)w_fwd,
+                     (f16*)w_bwd, Cout, Cin, taps, Kpad, Kpad_t);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
+extern "C" int od_pred_grad_to_level(od_ctx* ctx, const float* grad_pred, void* dz, int B, int P, int C, int row_off,
+                                     int rows, float loss_scale, void* stream) {
+  OD_REQUIRE(ctx && grad_pred && dz && B > 0 && P > 0 && C > 0 && rows > 0 && row_off >= 0 && row_off + rows <= P,
+             "od_pred_grad_to_level: bad argument");
+  const long long n = (long long)rows * C;
+  hipLaunchKernelGGL(od_pred_grad_level_k, dim3(grid_for(((long long)B * n + 7) / 8)), dim3(256), 0, (hipStream_t)stream,
+                     grad_pred, (f16*)dz, B, (long long)P * C, (long long)row_off * C, n, loss_scale);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}

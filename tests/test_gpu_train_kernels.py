@@ -1,0 +1,138 @@
+"""GPU parity of the training-side kernels (K11/K12) against torch-CPU autograd in fp32/fp64 on the same seeded inputs.
+Tolerances: f16 storage of activations/gradients (rtol 2^-9) + f32 accumulation-order noise."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _act_t(a, act, alpha):
+    if act == "leaky":
+        return F.leaky_relu(a, alpha)
+    if act == "elu":
+        return F.elu(a, alpha)
+    return a
+
+
+@pytest.mark.parametrize("C,act", [(32, "leaky"), (256, "elu"), (1024, "leaky"), (208, None)])
+def test_bn_forward_backward(cuda, C, act):
+    from object_detector_amd import train_ops as T
+    rng = np.random.default_rng(C)
+    B, H, W = 3, 6, 10
+    alpha = 0.1 if act == "leaky" else 1.0
+    z = rng.normal(0.3, 1.5, (B, H, W, C)).astype(np.float16)
+    gamma = rng.uniform(0.5, 1.5, C).astype(np.float32)
+    beta = rng.normal(0, 0.2, C).astype(np.float32)
+    dy = rng.normal(0, 1, (B, H, W, C)).astype(np.float16)
+    zt = torch.tensor(z.astype(np.float64), requires_grad=True)
+    gt = torch.tensor(gamma.astype(np.float64), requires_grad=True)
+    bt = torch.tensor(beta.astype(np.float64), requires_grad=True)
+    mu = zt.mean((0, 1, 2)); var = zt.var((0, 1, 2), unbiased=False)
+    xh = (zt - mu) / torch.sqrt(var + 1e-3)
+    y = _act_t(gt * xh + bt, act, alpha)
+    y.backward(torch.tensor(dy.astype(np.float64)))
+
+    zd, dyd = torch.from_numpy(z).to(cuda), torch.from_numpy(dy).to(cuda)
+    gd, bd = torch.from_numpy(gamma).to(cuda), torch.from_numpy(beta).to(cuda)
+    mean, rstd, scale, shift = T.bn_stats(zd, gd, bd, 1e-3)
+    np.testing.assert_allclose(mean.cpu().numpy(), mu.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rstd.cpu().numpy(), (1 / torch.sqrt(var + 1e-3)).detach().numpy(), rtol=1e-4)
+    yd = T.scale_act(zd, scale, shift, act, alpha).cpu().numpy().astype(np.float64)
+    yr = y.detach().numpy()
+    assert (np.abs(yd - yr) <= 2e-3 + 2.0 ** -9 * np.abs(yr)).all()
+    dz, dgamma, dbeta = T.bn_bwd(zd, dyd, scale, shift, mean, rstd, act, alpha, bn=True)
+    np.testing.assert_allclose(dgamma.cpu().numpy(), gt.grad.numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(dbeta.cpu().numpy(), bt.grad.numpy(), rtol=2e-3, atol=2e-3)
+    dzr = zt.grad.numpy()
+    dzd = dz.cpu().numpy().astype(np.float64)
+    assert (np.abs(dzd - dzr) <= 3e-3 * max(1.0, np.abs(dzr).max()) + 2.0 ** -9 * np.abs(dzr)).all()
+
+
+def test_bias_layer_backward(cuda):
+    """prediction conv: no BN, linear: dz = dy, dbias = sum dy"""
+    from object_detector_amd import train_ops as T
+    rng = np.random.default_rng(1)
+    z = rng.normal(0, 1, (2, 5, 5, 208)).astype(np.float16)
+    dy = rng.normal(0, 1, (2, 5, 5, 208)).astype(np.float16)
+    one = torch.ones(208, device=cuda); bias = torch.zeros(208, device=cuda)
+    dz, dg, db = T.bn_bwd(torch.from_numpy(z).to(cuda), torch.from_numpy(dy).to(cuda), one, bias, None, None, None, 0.0,
+                          bn=False)
+    assert (dz.cpu().numpy() == dy).all()
+    np.testing.assert_allclose(db.cpu().numpy(), dy.astype(np.float64).sum((0, 1, 2)), rtol=1e-4, atol=1e-3)
+
+
+CONV_CASES = [  # B, H, W, Cin, Cout, k, stride
+    (2, 12, 12, 64, 128, 3, 1),
+    (2, 12, 12, 64, 128, 3, 2),
+    (3, 10, 10, 128, 64, 1, 1),
+    (2, 16, 16, 32, 64, 3, 1),     # Cin=32: column tile spans 4 taps in the weight gradient
+    (2, 8, 8, 256, 208, 3, 1),     # ragged Cout (208)
+    (1, 20, 20, 128, 256, 3, 2),
+    (2, 6, 10, 1024, 512, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv_backward(cuda, case):
+    from object_detector_amd import train_ops as T
+    B, H, W, Cin, Cout, k, stride = case
+    rng = np.random.default_rng(hash(case) & 0xFFFF)
+    x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float16)
+    w = (rng.normal(0, 1, (Cout, k, k, Cin)) * np.sqrt(2.0 / (k * k * Cin))).astype(np.float16)
+    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    dz = rng.normal(0, 1, (B, Ho, Wo, Cout)).astype(np.float16)
+    xt = torch.tensor(x.astype(np.float64)).permute(0, 3, 1, 2).requires_grad_(True)
+    wt = torch.tensor(w.astype(np.float64)).permute(0, 3, 1, 2).requires_grad_(True)
+    y = F.conv2d(xt, wt, stride=stride, padding=k // 2)
+    y.backward(torch.tensor(dz.astype(np.float64)).permute(0, 3, 1, 2))
+    dx_ref = xt.grad.permute(0, 2, 3, 1).numpy()
+    dw_ref = wt.grad.permute(0, 2, 3, 1).numpy().reshape(Cout, k * k * Cin)
+
+    xd, dzd = torch.from_numpy(x).to(cuda), torch.from_numpy(dz).to(cuda)
+    wm = torch.from_numpy(w.astype(np.float32).reshape(Cout, -1)).to(cuda)
+    wf, wb = T.pack_weights(wm, Cout, Cin, k)
+    # pack layout check (forward)
+    assert (wf.cpu().numpy()[:Cout, :k * k * Cin] == w.reshape(Cout, -1)).all()
+    # backward-data
+    ones = torch.ones(wb.shape[0], device=cuda); zeros = torch.zeros(wb.shape[0], device=cuda)
+    dx = T.conv_packed(dzd, wb, ones, zeros, Cout, Cin, k, stride=stride, transposed=(stride == 2))
+    dxd = dx.cpu().numpy().astype(np.float64)
+    assert dxd.shape == dx_ref.shape
+    tol = 2e-3 * max(1.0, np.abs(dx_ref).max()) + 2.0 ** -9 * np.abs(dx_ref)
+    assert (np.abs(dxd - dx_ref) <= tol).all(), np.abs(dxd - dx_ref).max()
+    # gradient accumulation through the epilogue's residual input
+    acc = torch.from_numpy(rng.normal(0, 1, dx_ref.shape).astype(np.float16)).to(cuda)
+    dx2 = T.conv_packed(dzd, wb, ones, zeros, Cout, Cin, k, stride=stride, transposed=(stride == 2), res=acc,
+                        res_mode="same").cpu().numpy().astype(np.float64)
+    ref2 = dx_ref + acc.cpu().numpy().astype(np.float64)
+    assert (np.abs(dx2 - ref2) <= tol + 2.0 ** -9 * np.abs(ref2) + 1e-3).all()
+    # backward-weight (f32, atomics: order noise only)
+    dw = T.conv_bwd_weight(xd, dzd, Cin, Cout, k, stride).cpu().numpy()[:Cout, :k * k * Cin]
+    np.testing.assert_allclose(dw, dw_ref, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(dw_ref).max()))
+    # accumulation into an existing buffer (shared prediction module)
+    dw_t = T.conv_bwd_weight(xd, dzd, Cin, Cout, k, stride)
+    T.conv_bwd_weight(xd, dzd, Cin, Cout, k, stride, dw=dw_t)
+    np.testing.assert_allclose(dw_t.cpu().numpy()[:Cout, :k * k * Cin], 2 * dw_ref, rtol=2e-3,
+                               atol=4e-3 * max(1.0, np.abs(dw_ref).max()))
+
+
+def test_down2_and_sgd(cuda):
+    from object_detector_amd import train_ops as T
+    rng = np.random.default_rng(2)
+    d = rng.normal(0, 1, (2, 8, 12, 64)).astype(np.float16)
+    up = T.down2_sum_add(torch.from_numpy(d).to(cuda)).cpu().numpy()
+    ref = d.astype(np.float32).reshape(2, 4, 2, 6, 2, 64).sum((2, 4))
+    np.testing.assert_allclose(up.astype(np.float32), ref, rtol=2e-3, atol=2e-3)
+    base = torch.from_numpy(rng.normal(0, 1, up.shape).astype(np.float16)).to(cuda)
+    up2 = T.down2_sum_add(torch.from_numpy(d).to(cuda), base.clone()).cpu().numpy().astype(np.float32)
+    np.testing.assert_allclose(up2, ref + base.cpu().numpy().astype(np.float32), rtol=4e-3, atol=4e-3)
+    n = 10007
+    w = rng.normal(0, 1, n).astype(np.float32); m = rng.normal(0, 1, n).astype(np.float32)
+    g = rng.normal(0, 1, n).astype(np.float32)
+    wd, md = torch.from_numpy(w).to(cuda), torch.from_numpy(m).to(cuda)
+    T.sgd_step(wd, md, torch.from_numpy(g).to(cuda), lr=0.1, momentum=0.9, weight_decay=1e-4, inv_loss_scale=1 / 128)
+    mr = 0.9 * m + (g / 128 + 1e-4 * w)
+    np.testing.assert_allclose(md.cpu().numpy(), mr, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(wd.cpu().numpy(), w - 0.1 * mr, rtol=1e-6, atol=1e-7)
