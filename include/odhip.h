@@ -193,6 +193,22 @@ int od_sgd_step(od_ctx* ctx, float* w, float* m, const float* g, long long n, fl
  * [Cin_pad][Kpad_t] (taps flipped, channels swapped); both destinations must be pre-zeroed once (padding) */
 int od_pack_weights(od_ctx* ctx, const float* w, void* w_fwd, void* w_bwd, int Cout, int Cin, int ksize, void* stream);
 
+/* first layer's weight gradient: dw f32 [32][27] += dz^T . shifted(x_u8) * in_scale (no dX: the input is the image) */
+int od_conv_first_bwd_weight(od_ctx* ctx, const uint8_t* x, const void* dz, float* dw, int B, int H, int W, int Cout,
+                             float in_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K13: data-parallel gradient exchange over RCCL / xGMI (reference knob use_multi_gpu=True, check_assign.py:19).
+ * One process per GPU; the launcher (Python) creates the unique id on rank 0 (od_comm_get_unique_id) and ships it to
+ * the other ranks itself.  od_allreduce: in-place sum over ranks, asynchronous on `stream`.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct od_comm od_comm;
+int od_comm_unique_id_bytes(void);
+int od_comm_get_unique_id(void* out, int bytes);
+int od_comm_init(od_ctx* ctx, int rank, int nranks, const void* unique_id, od_comm** out);
+int od_allreduce(od_comm* comm, void* buf, long long count, int dtype, void* stream);
+int od_comm_destroy(od_comm* comm);
+
 /* ------------------------------------------------------------------------------------------------
  * Native forward plan: the whole layer list of one network executed from C++ (one call per batch, optional
  * hipGraph replay) so Python is not in the per-layer loop.  ops is an array of od_plan_op.

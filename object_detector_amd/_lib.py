@@ -93,6 +93,13 @@ _PROTOS = {
                               C.c_float, C.c_float, C.c_void_p]),
     "od_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p]),
+    "od_conv_first_bwd_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_float, C.c_void_p]),
+    "od_comm_unique_id_bytes": (C.c_int, []),
+    "od_comm_get_unique_id": (C.c_int, [C.c_void_p, C.c_int]),
+    "od_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "od_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
+    "od_comm_destroy": (C.c_int, [C.c_void_p]),
     "od_plan_create": (C.c_int, [C.c_void_p, C.POINTER(PlanOp), C.c_int, C.POINTER(C.c_void_p)]),
     "od_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
     "od_plan_capture": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -107,3 +107,64 @@ extern "C" int od_conv_first_fwd(od_ctx* ctx, const uint8_t* x, const void* w, c
   OD_CHECK_LAUNCH();
   return OD_OK;
 }
+
+// ---- K11 for the first layer: dW[co][tap*3 + c] += sum_pixels dz[pixel][co] * x_u8[shifted pixel][c] * in_scale -----
+// Tiny output (32 x 27), huge reduction: VALU kernel, one 8x32-pixel tile per workgroup, halo in LDS, per-workgroup
+// partial sums reduced through LDS, one f32 atomic per (co, k) per workgroup.  No dX (the input is the image).
+namespace {
+__global__ __launch_bounds__(256) void od_conv_first_wgrad(const uint8_t* __restrict__ x, const f16* __restrict__ dz,
+                                                           float* __restrict__ dw, int H, int W, float in_scale) {
+  __shared__ uint8_t tile[LH * LW * 4];
+  __shared__ float red[8][32][28];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, b = blockIdx.z;
+  for (int i = tid; i < LH * LW; i += 256) tile[i * 4 + 3] = 0;
+  for (int i = tid; i < LH * ROWB; i += 256) {
+    const int r = i / ROWB, bt = i - r * ROWB;
+    const int px = bt / 3, c = bt - px * 3;
+    const int gy = y0 - 1 + r, gx = x0 - 1 + px;
+    uint8_t v = 0;
+    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = x[((long long)(b * H + gy) * W + gx) * 3 + c];
+    tile[(r * LW + px) * 4 + c] = v;
+  }
+  __syncthreads();
+  const int co = tid & 31, part = tid >> 5;  // part = tile row (8 rows of 32 pixels)
+  float acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+  const int gy = y0 + part;
+  if (gy < H) {
+    for (int xx = 0; xx < TW; ++xx) {
+      const int gx = x0 + xx;
+      if (gx >= W) break;
+      const float d = (float)dz[((long long)(b * H + gy) * W + gx) * 32 + co];
+      const uint8_t* pb = tile + (part * LW + xx) * 4;
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        const int tap = k / 3, c = k - tap * 3;
+        acc[k] += d * (float)pb[((tap / 3) * LW + tap % 3) * 4 + c];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) red[part][co][k] = acc[k];
+  __syncthreads();
+  for (int i = tid; i < 32 * 27; i += 256) {
+    const int c2 = i / 27, k = i - c2 * 27;
+    float s = 0.f;
+#pragma unroll
+    for (int p2 = 0; p2 < 8; ++p2) s += red[p2][c2][k];
+    atomicAdd(dw + c2 * 27 + k, s * in_scale);
+  }
+}
+}  // namespace
+
+extern "C" int od_conv_first_bwd_weight(od_ctx* ctx, const uint8_t* x, const void* dz, float* dw, int B, int H, int W,
+                                        int Cout, float in_scale, void* stream) {
+  OD_REQUIRE(ctx && x && dz && dw && Cout == 32 && B > 0 && H > 0 && W > 0 && B <= 65535,
+             "od_conv_first_bwd_weight: bad argument (Cout must be 32)");
+  dim3 grid(od_ceil_div(W, TW), od_ceil_div(H, TH), B);
+  hipLaunchKernelGGL(od_conv_first_wgrad, grid, dim3(256), 0, (hipStream_t)stream, x, (const f16*)dz, dw, H, W, in_scale);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}

@@ -1,4 +1,4 @@
-// K11 (backward-weight): dW[co][tap*Cin + ci] += sum_m dZ[m][co] * X[shift_tap(m)][ci]   (3x3 / 1x1, stride 1 / 2)
+// K11 (backward-weight): dW[co][tap*Cin + ci] (dense f32 [Cout][k*k*Cin]) += sum_m dZ[m][co] * X[shift_tap(m)][ci]   (3x3 / 1x1, stride 1 / 2)
 //
 // GEMM with the PIXEL index as the reduction dimension: out tile = 128 output channels x 128 (tap, ci) columns, each
 // workgroup reduces a contiguous slice of the M = B*Ho*Wo pixels (split-K over workgroups) and adds its f32 partial tile
@@ -19,7 +19,7 @@ typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 struct WgradKP {
   const f16* x;    // [B,H,W,Cin]
   const f16* dz;   // [B,Ho,Wo,Cout]
-  float* dw;       // [Cout_pad][Kstride] f32
+  float* dw;       // [Cout][Ktot] f32, dense (the layout of the f32 master weights)
   const f16* zero;
   int H, W, Cin, Ho, Wo, Cout, ks, stride, pad;
   int Kstride, Ktot, M, HoWo;
@@ -187,7 +187,7 @@ extern "C" int od_conv2d_bwd_weight(od_ctx* ctx, const void* x, const void* dz, 
   p.Wo = (W + 2 * p.pad - ksize) / stride + 1;
   p.Cout = Cout;
   p.Ktot = ksize * ksize * Cin;
-  p.Kstride = od_round_up(p.Ktot, 64);
+  p.Kstride = p.Ktot;
   const long long M64 = (long long)B * p.Ho * p.Wo;
   OD_REQUIRE(M64 * Cout < (1LL << 31) && (long long)B * H * W * Cin < (1LL << 31), "od_conv2d_bwd_weight: too large");
   p.M = (int)M64;

@@ -62,12 +62,11 @@ def bn_bwd(z, dy, scale, shift, mean, rstd, act=None, alpha=0.0, bn=True, dgamma
 
 
 def conv_bwd_weight(x, dz, Cin, Cout, ksize, stride, dw=None):
-    """x f16 [B,H,W,Cin], dz f16 [B,Ho,Wo,Cout] -> dw f32 [Cout_pad, Kpad] (accumulated into `dw` when given)"""
+    """x f16 [B,H,W,Cin], dz f16 [B,Ho,Wo,Cout] -> dw f32 [Cout, k*k*Cin] dense (accumulated into `dw` when given)"""
     ctx = _ctx(x)
     B, H, W, _ = x.shape
-    cout_pad, kpad = _lib.conv_weight_dims(Cout, Cin, ksize)
     if dw is None:
-        dw = torch.zeros((cout_pad, kpad), dtype=torch.float32, device=x.device)
+        dw = torch.zeros((Cout, ksize * ksize * Cin), dtype=torch.float32, device=x.device)
     _lib.check(ctx.lib.od_conv2d_bwd_weight(ctx.handle, x.data_ptr(), dz.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout,
                                             ksize, stride, _stream_ptr()), "od_conv2d_bwd_weight")
     return dw

@@ -1,0 +1,371 @@
+"""Training step of the detector on MI355X: forward in BatchNorm-training mode, prior-box assignment, loss,
+backward through every conv / BN / activation, data-parallel gradient all-reduce, SGD with per-layer LR multipliers.
+
+reference: the (unseen) `fit` path of tk.dl.od.ObjectDetector -- generator -> encode_truth (check_assign.py:21) ->
+losses (docs/MODEL.md:33-52) -> per-layer learning rates (docs/MODEL.md:84-90: shared prediction-module layers x 1/3,
+base network x 1/100).  Every tensor op is a libodhip.so kernel; torch owns the HBM buffers and the process group.
+
+Numerics: activations and activation gradients f16 (gradients multiplied by `loss_scale`), MFMA accumulation and all
+statistics / parameter gradients / master weights f32.  BatchNorm statistics are per rank [BUILD-DEFINED, SURVEY.md §7];
+only gradients are exchanged.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, train_ops as T, weights as W
+from .net import Context, _stream_ptr
+from .pb import PriorBoxes
+
+BN_MOMENTUM = 0.99  # Keras default
+
+
+def lr_multiplier(name: str) -> float:
+    """docs/MODEL.md:84-90"""
+    if name.startswith("b."):
+        return 0.01
+    if name.startswith("h."):
+        return 1.0 / 3.0
+    return 1.0
+
+
+class _Node:
+    __slots__ = ("name", "x", "out", "res", "res_mode", "H", "W", "Cin", "Cout", "k", "stride", "act", "bn", "z",
+                 "mean", "rstd", "scale", "shift", "first", "pred_off", "pred_rows", "need_dx")
+
+
+class Trainer:
+    def __init__(self, params, batch_size, input_size=(320, 320), device="cuda:0", lr=1e-3, momentum=0.9,
+                 weight_decay=0.0, loss_scale=1024.0, box_mode="smooth_l1", backbone_act=("leaky", 0.1),
+                 head_act=("elu", 1.0), comm=None, world_size=1):
+        self.ctx = Context.get(device)
+        self.lib = self.ctx.lib
+        self.device = torch.device(device)
+        self.B = int(batch_size)
+        self.H0, self.W0 = int(input_size[0]), int(input_size[1])
+        self.num_classes, self.neck_ch, self.tower = W.infer_arch(params)
+        self.C = self.num_classes + 6
+        self.lr, self.momentum, self.weight_decay = float(lr), float(momentum), float(weight_decay)
+        self.loss_scale, self.box_mode = float(loss_scale), box_mode
+        self.comm, self.world = comm, int(world_size)
+        self.pb = PriorBoxes((self.H0, self.W0), self.num_classes, device=self.device)
+        self.P = len(self.pb)
+        dev = self.device
+
+        # ---- flat f32 parameter / gradient / momentum buffers -------------------------------------------------
+        self.specs = {s[0]: s for s in W.layer_specs(self.num_classes, self.neck_ch, self.tower)}
+        self.seg = {}  # (layer, kind) -> (offset, numel)
+        off = 0
+        for name, (_n, cin, cout, k, _s, bn) in self.specs.items():
+            for kind, n in (("w", cout * k * k * cin),) + ((("gamma", cout), ("beta", cout)) if bn else (("bias", cout),)):
+                self.seg[(name, kind)] = (off, n)
+                off += (n + 3) // 4 * 4
+        self.n_flat = off
+        host = np.zeros(off, np.float32)
+        for (name, kind), (o, n) in self.seg.items():
+            host[o:o + n] = np.asarray(params[f"{name}.{kind}"], np.float32).reshape(-1)
+        self.params = torch.from_numpy(host).to(dev)
+        self.grads = torch.zeros_like(self.params)
+        self.mom = torch.zeros_like(self.params)
+        self.run_mean = {n: torch.from_numpy(np.asarray(params[n + ".mean"], np.float32)).to(dev)
+                         for n, s in self.specs.items() if s[5]}
+        self.run_var = {n: torch.from_numpy(np.asarray(params[n + ".var"], np.float32)).to(dev)
+                        for n, s in self.specs.items() if s[5]}
+        maxpad = 2048
+        self.ones = torch.ones(maxpad, dtype=torch.float32, device=dev)
+        self.zeros = torch.zeros(maxpad, dtype=torch.float32, device=dev)
+        self.in_scale = torch.full((32,), 1.0 / 255.0, dtype=torch.float32, device=dev)
+        self.scratch = torch.zeros(maxpad, dtype=torch.float32, device=dev)  # sink for unused per-channel outputs
+        # ---- f16 packs ------------------------------------------------------------------------------------------
+        self.wf, self.wb = {}, {}
+        for name, (_n, cin, cout, k, _s, _bn) in self.specs.items():
+            if name == "b.conv0":
+                self.wf[name] = torch.zeros((32, 32), dtype=torch.float16, device=dev)
+                continue
+            cp, kp = _lib.conv_weight_dims(cout, cin, k)
+            self.wf[name] = torch.zeros((cp, kp), dtype=torch.float16, device=dev)
+            cp2, kp2 = _lib.conv_weight_dims(cin, cout, k)
+            self.wb[name] = torch.zeros((cp2, kp2), dtype=torch.float16, device=dev)
+        self._repack()
+        # ---- graph ------------------------------------------------------------------------------------------------
+        self.tensors = {"img": torch.zeros((self.B, self.H0, self.W0, 3), dtype=torch.uint8, device=dev)}
+        self.gradbuf = {}
+        self.nodes = []
+        self._build(backbone_act, head_act)
+        self.pred = torch.zeros((self.B, self.P, self.C), dtype=torch.float32, device=dev)
+        self.grad_pred = torch.zeros_like(self.pred)
+        self.losses = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.loss_ws = torch.empty(self.lib.od_loss_workspace_bytes(self.B, self.P), dtype=torch.uint8, device=dev)
+        mx = max(self.B * (n.H // n.stride) * (n.W // n.stride) * n.Cout for n in self.nodes)
+        self.dz = torch.empty(mx, dtype=torch.float16, device=dev)  # scratch: dz of the node being processed
+        mxc = max(self.lib.od_bn_workspace_bytes(self.B * (n.H // n.stride) * (n.W // n.stride), n.Cout) + 2 * n.Cout * 4
+                  for n in self.nodes)
+        self.bn_ws = torch.empty(mxc, dtype=torch.uint8, device=dev)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def view(self, buf, name, kind):
+        o, n = self.seg[(name, kind)]
+        return buf[o:o + n]
+
+    def _repack(self):
+        for name, (_n, cin, cout, k, _s, _bn) in self.specs.items():
+            w = self.view(self.params, name, "w")
+            if name == "b.conv0":
+                wf = self.wf[name]
+                wf.zero_()
+                wf[:, :27] = w.view(32, 27).to(torch.float16)  # 1.7 KB: plain torch copy is fine here
+                continue
+            _lib.check(self.lib.od_pack_weights(self.ctx.handle, w.data_ptr(), self.wf[name].data_ptr(),
+                                                self.wb[name].data_ptr(), cout, cin, k, _stream_ptr()), "od_pack_weights")
+
+    def _add_node(self, name, x, out, H, Wd, act, res=None, res_mode="none", first=False, pred_off=None, pred_rows=0,
+                  need_dx=True):
+        _n, cin, cout, k, stride, bn = self.specs[name]
+        n = _Node()
+        n.name, n.x, n.out, n.res, n.res_mode = name, x, out, res, res_mode
+        n.H, n.W, n.Cin, n.Cout, n.k, n.stride, n.act, n.bn = H, Wd, cin, cout, k, stride, act, bn
+        n.first, n.pred_off, n.pred_rows, n.need_dx = first, pred_off, pred_rows, need_dx
+        Ho, Wo = H // stride, Wd // stride
+        dev = self.device
+        if pred_off is None:
+            n.z = torch.empty((self.B, Ho, Wo, cout), dtype=torch.float16, device=dev)
+            self.tensors[out] = torch.empty((self.B, Ho, Wo, cout), dtype=torch.float16, device=dev)
+            n.mean, n.rstd, n.scale, n.shift = (torch.empty(cout, dtype=torch.float32, device=dev) for _ in range(4))
+        else:
+            n.z = None
+        self.nodes.append(n)
+        return Ho, Wo
+
+    def _build(self, bact, hact):
+        H, Wd = self._add_node("b.conv0", "img", "t0", self.H0, self.W0, bact, first=True, need_dx=False)
+        cur = "t0"
+        taps = []
+        for si, (nblk, _ch) in enumerate(W.STAGES, start=1):
+            H, Wd = self._add_node(f"b.down{si}", cur, f"s{si}.d", H, Wd, bact)
+            cur = f"s{si}.d"
+            for r in range(nblk):
+                self._add_node(f"b.s{si}.{r}.a", cur, f"s{si}.{r}.a", H, Wd, bact)
+                self._add_node(f"b.s{si}.{r}.b", f"s{si}.{r}.a", f"s{si}.{r}.b", H, Wd, bact, res=cur, res_mode="same")
+                cur = f"s{si}.{r}.b"
+            taps.append((cur, H, Wd))
+        (c3, h3, w3), (c4, h4, w4), (c5, h5, w5) = taps[2], taps[3], taps[4]
+        self._add_node("n.lat5", c5, "p5", h5, w5, hact)
+        self._add_node("n.lat4", c4, "m4", h4, w4, hact, res="p5", res_mode="up2")
+        self._add_node("n.out4", "m4", "p4", h4, w4, hact)
+        self._add_node("n.lat3", c3, "m3", h3, w3, hact, res="p4", res_mode="up2")
+        self._add_node("n.out3", "m3", "p3", h3, w3, hact)
+        off = 0
+        for li, (lv, h, w) in enumerate((("p3", h3, w3), ("p4", h4, w4), ("p5", h5, w5))):
+            cur = lv
+            for t in range(self.tower):
+                self._add_node(f"h.t{t}", cur, f"L{li}.t{t}", h, w, hact)
+                cur = f"L{li}.t{t}"
+            rows = h * w * W.NUM_PRIORS
+            self._add_node("h.out", cur, f"L{li}.out", h, w, None, pred_off=off, pred_rows=rows)
+            off += rows
+        assert off == self.P
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _conv_raw(self, n, x, out, out_f32=False, obs=0, ops=0, bias=None):
+        d = _lib.ConvDesc()
+        d.x, d.w = x.data_ptr(), self.wf[n.name].data_ptr()
+        d.scale, d.bias = self.ones.data_ptr(), (bias if bias is not None else self.zeros).data_ptr()
+        d.out = out if isinstance(out, int) else out.data_ptr()
+        d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride = self.B, n.H, n.W, n.Cin, n.Cout, n.k, n.stride
+        d.act, d.res_mode, d.tile_cfg = _lib.OD_ACT_LINEAR, _lib.OD_RES_NONE, -1
+        d.out_dtype = _lib.OD_DT_F32 if out_f32 else _lib.OD_DT_F16
+        d.out_batch_stride, d.out_pix_stride = obs, ops
+        _lib.check(self.lib.od_conv2d_fwd(self.ctx.handle, C.byref(d), _stream_ptr()), f"conv fwd {n.name}")
+
+    def forward(self, x_u8):
+        """uint8 [B,H,W,3] (device) -> pred f32 [B,P,C]; keeps z / statistics of every layer for the backward pass."""
+        self.tensors["img"].copy_(x_u8, non_blocking=True)
+        lib, h = self.lib, self.ctx.handle
+        s = _stream_ptr()
+        for n in self.nodes:
+            x = self.tensors[n.x]
+            if n.first:
+                _lib.check(lib.od_conv_first_fwd(h, x.data_ptr(), self.wf[n.name].data_ptr(), self.in_scale.data_ptr(),
+                                                 self.zeros.data_ptr(), n.z.data_ptr(), self.B, n.H, n.W, n.Cout,
+                                                 _lib.OD_ACT_LINEAR, 0.0, s), "conv_first")
+            elif n.pred_off is not None:
+                bias = self.view(self.params, n.name, "bias")
+                if bias.numel() < 256:  # scale/bias vectors are read in whole 256-channel pads
+                    bp = getattr(self, "_bias_pad", None)
+                    if bp is None:
+                        bp = self._bias_pad = torch.zeros(256, dtype=torch.float32, device=self.device)
+                    bp[:bias.numel()].copy_(bias)
+                    bias = bp
+                self._conv_raw(n, x, self.pred.data_ptr() + n.pred_off * self.C * 4, out_f32=True, obs=self.P * self.C,
+                               ops=n.Cout, bias=bias)
+                continue
+            else:
+                self._conv_raw(n, x, n.z)
+            M = n.z.numel() // n.Cout
+            wsb = lib.od_bn_workspace_bytes(M, n.Cout)
+            _lib.check(lib.od_bn_stats(h, n.z.data_ptr(), M, n.Cout, self.view(self.params, n.name, "gamma").data_ptr(),
+                                       self.view(self.params, n.name, "beta").data_ptr(), W.BN_EPS, n.mean.data_ptr(),
+                                       n.rstd.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
+                                       self.run_mean[n.name].data_ptr(), self.run_var[n.name].data_ptr(), BN_MOMENTUM,
+                                       self.bn_ws.data_ptr(), wsb, s), "od_bn_stats")
+            y = self.tensors[n.out]
+            res = self.tensors[n.res] if n.res else None
+            rm = {"none": 0, "same": 1, "up2": 2}[n.res_mode]
+            Ho, Wo = n.H // n.stride, n.W // n.stride
+            _lib.check(lib.od_scale_act(h, n.z.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
+                                        res.data_ptr() if res is not None else None, rm, y.data_ptr(), self.B, Ho, Wo,
+                                        n.Cout, _lib.ACT_ENUM[n.act[0] if n.act else None],
+                                        float(n.act[1]) if n.act else 0.0, s), "od_scale_act")
+        return self.pred
+
+    def loss(self, y_target):
+        """pred (from forward) + targets f32 [B,P,C] -> losses [4] on device; fills grad_pred."""
+        _lib.check(self.lib.od_loss_fwd_bwd(self.ctx.handle, self.pred.data_ptr(), y_target.data_ptr(),
+                                            self.grad_pred.data_ptr(), self.losses.data_ptr(), self.B, self.P,
+                                            self.num_classes, 0.25, 2.0, {"smooth_l1": 0, "mse": 1}[self.box_mode], 1.0,
+                                            1.0, 1.0, self.loss_ws.data_ptr(), self.loss_ws.numel(), _stream_ptr()),
+                   "od_loss_fwd_bwd")
+        return self.losses
+
+    def _grad(self, key):
+        t = self.gradbuf.get(key)
+        if t is None:
+            t = self.gradbuf[key] = torch.empty_like(self.tensors[key])
+        return t
+
+    def backward(self):
+        """grad_pred -> self.grads (f32, loss-scaled sums over this rank's batch)."""
+        lib, h = self.lib, self.ctx.handle
+        s = _stream_ptr()
+        self.grads.zero_()
+        have = set()
+        for n in reversed(self.nodes):
+            Ho, Wo = n.H // n.stride, n.W // n.stride
+            M = self.B * Ho * Wo
+            dz = self.dz[:M * n.Cout]
+            wsb = lib.od_bn_workspace_bytes(M, n.Cout) + 2 * n.Cout * 4
+            if n.pred_off is not None:
+                _lib.check(lib.od_pred_grad_to_level(h, self.grad_pred.data_ptr(), dz.data_ptr(), self.B, self.P, self.C,
+                                                     n.pred_off, n.pred_rows, self.loss_scale, s), "od_pred_grad_to_level")
+                _lib.check(lib.od_bn_bwd(h, dz.data_ptr(), dz.data_ptr(), self.ones.data_ptr(), self.zeros.data_ptr(),
+                                         None, None, M, n.Cout, _lib.OD_ACT_LINEAR, 0.0, 0,
+                                         self.scratch.data_ptr(), self.view(self.grads, n.name, "bias").data_ptr(),
+                                         dz.data_ptr(), self.bn_ws.data_ptr(), wsb, s), "od_bn_bwd(bias)")
+            else:
+                assert n.out in have, f"no gradient reached {n.out}"
+                dy = self.gradbuf[n.out]
+                if n.res:
+                    g = self._grad(n.res)
+                    if n.res_mode == "same":
+                        if n.res in have:
+                            _lib.check(lib.od_add_f16(h, g.data_ptr(), dy.data_ptr(), dy.numel(), s), "od_add_f16")
+                        else:
+                            g.copy_(dy)
+                    else:
+                        _lib.check(lib.od_down2_sum_add(h, dy.data_ptr(), g.data_ptr(), self.B, Ho // 2, Wo // 2, n.Cout,
+                                                        int(n.res in have), s), "od_down2_sum_add")
+                    have.add(n.res)
+                _lib.check(lib.od_bn_bwd(h, n.z.data_ptr(), dy.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
+                                         n.mean.data_ptr(), n.rstd.data_ptr(), M, n.Cout,
+                                         _lib.ACT_ENUM[n.act[0] if n.act else None], float(n.act[1]) if n.act else 0.0, 1,
+                                         self.view(self.grads, n.name, "gamma").data_ptr(),
+                                         self.view(self.grads, n.name, "beta").data_ptr(), dz.data_ptr(),
+                                         self.bn_ws.data_ptr(), wsb, s), f"od_bn_bwd {n.name}")
+            dw = self.view(self.grads, n.name, "w")
+            x = self.tensors[n.x]
+            if n.first:
+                _lib.check(lib.od_conv_first_bwd_weight(h, x.data_ptr(), dz.data_ptr(), dw.data_ptr(), self.B, n.H, n.W,
+                                                        n.Cout, 1.0 / 255.0, s), "od_conv_first_bwd_weight")
+                continue
+            _lib.check(lib.od_conv2d_bwd_weight(h, x.data_ptr(), dz.data_ptr(), dw.data_ptr(), self.B, n.H, n.W, n.Cin,
+                                                n.Cout, n.k, n.stride, s), f"wgrad {n.name}")
+            if not n.need_dx:
+                continue
+            g = self._grad(n.x)
+            d = _lib.ConvDesc()
+            d.x, d.w, d.scale, d.bias = dz.data_ptr(), self.wb[n.name].data_ptr(), self.ones.data_ptr(), self.zeros.data_ptr()
+            d.out = g.data_ptr()
+            d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride = self.B, Ho, Wo, n.Cout, n.Cin, n.k, n.stride
+            d.act, d.out_dtype, d.tile_cfg = _lib.OD_ACT_LINEAR, _lib.OD_DT_F16, -1
+            d.transposed = int(n.stride == 2)
+            if n.x in have:
+                d.res, d.res_mode = g.data_ptr(), _lib.OD_RES_SAME  # accumulate in place
+            else:
+                d.res, d.res_mode = None, _lib.OD_RES_NONE
+            _lib.check(lib.od_conv2d_fwd(h, C.byref(d), s), f"dgrad {n.name}")
+            have.add(n.x)
+        # shared-layer BN gradients were accumulated over the three levels inside od_bn_bwd
+        return self.grads
+
+    def allreduce(self):
+        """Sum the flat f32 gradient buffer over the data-parallel ranks (ONE collective per step: 47 M floats)."""
+        if self.world <= 1:
+            return
+        if self.comm is not None:
+            _lib.check(self.lib.od_allreduce(self.comm, self.grads.data_ptr(), self.n_flat, _lib.OD_DT_F32, _stream_ptr()),
+                       "od_allreduce")
+        else:
+            dp_allreduce_(self.grads)
+
+    def sgd(self):
+        inv = dp_effective_scale(self.loss_scale, self.world)  # grads are averaged over ranks
+        for (name, kind), (o, n) in self.seg.items():
+            lr = self.lr * lr_multiplier(name)
+            wd = self.weight_decay if kind == "w" else 0.0
+            _lib.check(self.lib.od_sgd_step(self.ctx.handle, self.params.data_ptr() + 4 * o, self.mom.data_ptr() + 4 * o,
+                                            self.grads.data_ptr() + 4 * o, n, lr, self.momentum, wd, inv, _stream_ptr()),
+                       "od_sgd_step")
+        self._repack()
+
+    def step(self, x_u8, annotations=None, y_target=None):
+        """One training step.  annotations: list[ObjectsAnnotation] (encoded on the device) or y_target [B,P,C]."""
+        if y_target is None:
+            y_target, _npos, _ = self.pb.encode_batch(annotations, return_device=True)
+        self.forward(x_u8)
+        self.loss(y_target)
+        self.backward()
+        self.allreduce()
+        self.sgd()
+        return self.losses
+
+    def export_params(self):
+        """-> dict in the weights.py format (masters + BatchNorm running statistics) for ObjectDetector(params, ...)."""
+        host = self.params.cpu().numpy()
+        out = {}
+        for (name, kind), (o, n) in self.seg.items():
+            _n, cin, cout, k, _s, _bn = self.specs[name]
+            a = host[o:o + n]
+            out[f"{name}.{kind}"] = a.reshape(cout, k, k, cin).copy() if kind == "w" else a.copy()
+        for name in self.run_mean:
+            out[name + ".mean"] = self.run_mean[name].cpu().numpy()
+            out[name + ".var"] = self.run_var[name].cpu().numpy()
+        return out
+
+
+def dp_allreduce_(flat: torch.Tensor):
+    """In-place sum over the ranks of the default process group (backend "nccl" = RCCL on GPUs, gloo in CPU tests)."""
+    torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM)
+    return flat
+
+
+def dp_effective_scale(loss_scale: float, world: int) -> float:
+    """od_sgd_step's inv_loss_scale: undo the loss scale and average the summed gradients over the ranks."""
+    return 1.0 / (loss_scale * world)
+
+
+def init_comm(ctx: Context):
+    """Create the RCCL communicator of this rank through the C ABI; the unique id travels over torch.distributed."""
+    rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+    nbytes = ctx.lib.od_comm_unique_id_bytes()
+    buf = (C.c_ubyte * nbytes)()
+    if rank == 0:
+        _lib.check(ctx.lib.od_comm_get_unique_id(buf, nbytes), "od_comm_get_unique_id")
+    box = [bytes(buf)]
+    torch.distributed.broadcast_object_list(box, src=0)
+    raw = (C.c_ubyte * nbytes).from_buffer_copy(box[0])
+    h = C.c_void_p()
+    _lib.check(ctx.lib.od_comm_init(ctx.handle, rank, world, raw, C.byref(h)), "od_comm_init")
+    return h, world

@@ -1,0 +1,75 @@
+"""Oracle for the training step: the same network in torch (CPU, float64, autograd), BatchNorm in training mode,
+loss gradient from oracle/loss.py.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Follows reference docs/MODEL.md:5-21 (network), :33-52 (losses), :84-90 (per-layer learning rates)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import loss as oloss
+from .network import BN_EPS, NUM_PRIORS, STAGES
+
+
+def _act(a, act):
+    if act is None:
+        return a
+    if act[0] == "leaky":
+        return F.leaky_relu(a, act[1])
+    return F.elu(a, act[1])
+
+
+class TorchDetector:
+    def __init__(self, params, backbone_act=("leaky", 0.1), head_act=("elu", 1.0), dtype=torch.float64):
+        self.p = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=not (k.endswith(".mean") or k.endswith(".var")))
+                  for k, v in params.items()}
+        self.bact, self.hact, self.dtype = backbone_act, head_act, dtype
+        self.tower = sum(1 for k in params if k.startswith("h.t") and k.endswith(".w"))
+
+    def conv(self, x, name, stride=1, act=None, res=None, up2=False):
+        w = self.p[name + ".w"].permute(0, 3, 1, 2)
+        z = F.conv2d(x, w, stride=stride, padding=w.shape[-1] // 2)
+        if name + ".gamma" in self.p:
+            mu = z.mean((0, 2, 3), keepdim=True)
+            var = z.var((0, 2, 3), unbiased=False, keepdim=True)
+            z = (z - mu) / torch.sqrt(var + BN_EPS)
+            z = z * self.p[name + ".gamma"].view(1, -1, 1, 1) + self.p[name + ".beta"].view(1, -1, 1, 1)
+        else:
+            z = z + self.p[name + ".bias"].view(1, -1, 1, 1)
+        y = _act(z, act)
+        if res is not None:
+            y = y + (F.interpolate(res, scale_factor=2, mode="nearest") if up2 else res)
+        return y
+
+    def forward(self, x_u8, num_classes=20):
+        x = torch.tensor(x_u8.astype(np.float64) / 255.0, dtype=self.dtype).permute(0, 3, 1, 2)
+        a, hh = self.bact, self.hact
+        x = self.conv(x, "b.conv0", act=a)
+        taps = []
+        for si, (n, _ch) in enumerate(STAGES, start=1):
+            x = self.conv(x, f"b.down{si}", stride=2, act=a)
+            for r in range(n):
+                t = self.conv(x, f"b.s{si}.{r}.a", act=a)
+                x = self.conv(t, f"b.s{si}.{r}.b", act=a, res=x)
+            taps.append(x)
+        c3, c4, c5 = taps[2], taps[3], taps[4]
+        p5 = self.conv(c5, "n.lat5", act=hh)
+        p4 = self.conv(self.conv(c4, "n.lat4", act=hh, res=p5, up2=True), "n.out4", act=hh)
+        p3 = self.conv(self.conv(c3, "n.lat3", act=hh, res=p4, up2=True), "n.out3", act=hh)
+        outs = []
+        C = 2 + num_classes + 4
+        for lv in (p3, p4, p5):
+            t = lv
+            for i in range(self.tower):
+                t = self.conv(t, f"h.t{i}", act=hh)
+            o = self.conv(t, "h.out").permute(0, 2, 3, 1)
+            outs.append(o.reshape(o.shape[0], -1, C))
+        return torch.cat(outs, 1)
+
+    def loss_and_grads(self, x_u8, y_target, num_classes=20, box_mode="smooth_l1"):
+        pred = self.forward(x_u8, num_classes)
+        losses, g = oloss.loss_and_grad(pred.detach().numpy(), y_target, num_classes, box_mode=box_mode)
+        pred.backward(torch.tensor(g, dtype=self.dtype))
+        grads = {k: v.grad.numpy() for k, v in self.p.items() if v.grad is not None}
+        return losses, grads, pred.detach().numpy()

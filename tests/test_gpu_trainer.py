@@ -1,0 +1,97 @@
+"""GPU parity of one whole training step (forward in BN-training mode, assignment, loss, backward, SGD) against the
+torch-CPU float64 oracle with the same seeded parameters, images and ground truth."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(cuda, B=2, S=96, seed=2):
+    from object_detector_amd import weights as W
+    from object_detector_amd.pb import ObjectsAnnotation
+    from oracle import network as onet
+    params = W.random_init(seed)
+    x = onet.synthetic_images(B, S, seed=0)
+    rng = np.random.default_rng(3)
+    anns = []
+    for _ in range(B):
+        n = int(rng.integers(1, 4))
+        c = rng.uniform(0.2, 0.8, (n, 2)); wh = rng.uniform(0.15, 0.6, (n, 2))
+        anns.append(ObjectsAnnotation(None, S, S, rng.integers(0, 20, n),
+                                      np.clip(np.concatenate([c - wh / 2, c + wh / 2], 1), 0, 1).astype(np.float32)))
+    return params, x, anns
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.mark.parametrize("backbone_act", [("elu", 1.0), ("leaky", 0.1)], ids=["smooth", "leaky"])
+def test_training_step_matches_torch_oracle(cuda, backbone_act):
+    """Gradients of every parameter vs the float64 torch oracle.  With a smooth activation everywhere the f16 pipeline
+    agrees to < 1 %; with the backbone's LeakyReLU the kink makes ~1 % of the units take the other slope than in the
+    float64 oracle (their pre-activation differs by the accumulated f16 rounding), which alone moves the gradient
+    direction by a few % -- so the leaky variant only gets the loose bound."""
+    from object_detector_amd.trainer import Trainer
+    from oracle.train_ref import TorchDetector
+    B, S = 2, 96
+    params, x, anns = _setup(cuda, B, S)
+    tr = Trainer(params, B, (S, S), device=cuda, lr=0.0, loss_scale=256.0, backbone_act=backbone_act)
+    y, _npos, _ = tr.pb.encode_batch(anns, return_device=True)
+    pred = tr.forward(torch.from_numpy(x).to(cuda)).clone()
+    losses = tr.loss(y).clone()
+    grads = tr.backward()
+    torch.cuda.synchronize()
+    ref_losses, ref_grads, ref_pred = TorchDetector(params, backbone_act=backbone_act).loss_and_grads(x, y.cpu().numpy())
+    assert np.abs(pred.cpu().numpy() - ref_pred).max() <= 3e-2 * max(1.0, np.abs(ref_pred).max())
+    np.testing.assert_allclose(losses.cpu().numpy(), ref_losses, rtol=3e-2)
+    g = grads.cpu().numpy() / 256.0
+    worst = {}
+    for (name, kind), (o, n) in tr.seg.items():
+        worst[(name, kind)] = _rel(g[o:o + n], ref_grads[f"{name}.{kind}"].reshape(-1))
+    top = sorted(worst.items(), key=lambda kv: -kv[1])
+    print("worst relative gradient errors:", top[:5], "median", np.median(list(worst.values())))
+    if backbone_act[0] == "elu":
+        assert max(worst.values()) < 0.01, top[:5]
+    else:
+        assert max(v for (n, k), v in worst.items() if not n.startswith("b.")) < 0.01  # neck / head are smooth (ELU)
+        assert max(worst.values()) < 0.15, top[:5]
+
+
+def test_sgd_step_lowers_loss_and_exports(cuda):
+    from object_detector_amd.detector import ObjectDetector
+    from object_detector_amd.trainer import Trainer, lr_multiplier
+    assert lr_multiplier("b.s3.0.a") == 0.01 and lr_multiplier("h.out") == pytest.approx(1 / 3) and lr_multiplier("n.lat5") == 1.0
+    B, S = 2, 96
+    params, x, anns = _setup(cuda, B, S)
+    tr = Trainer(params, B, (S, S), device=cuda, lr=0.01, momentum=0.0, loss_scale=256.0)
+    xt = torch.from_numpy(x).to(cuda)
+    first = float(tr.step(xt, anns)[3])
+    for _ in range(8):
+        last = float(tr.step(xt, anns)[3])
+    assert np.isfinite(last) and last < first, (first, last)
+    # exported parameters drive the inference path
+    od = ObjectDetector(tr.export_params(), B, (S, S), device=cuda)
+    keep, cnt = od.predict_batch_device(xt)
+    assert int(cnt.min()) >= 0
+
+
+def test_rccl_comm_single_rank(cuda):
+    """od_comm_* through the C ABI with a 1-rank communicator (the only topology a 1-GPU box offers): the all-reduce is
+    the identity and leaves the gradient buffer bit-identical; DP semantics proper are covered by the gloo test."""
+    import ctypes as C
+    from object_detector_amd import _lib
+    from object_detector_amd.net import Context
+    ctx = Context.get(cuda)
+    n = ctx.lib.od_comm_unique_id_bytes()
+    buf = (C.c_ubyte * n)()
+    _lib.check(ctx.lib.od_comm_get_unique_id(buf, n))
+    h = C.c_void_p()
+    _lib.check(ctx.lib.od_comm_init(ctx.handle, 0, 1, buf, C.byref(h)))
+    g = torch.randn(100003, device=cuda)
+    ref = g.clone()
+    _lib.check(ctx.lib.od_allreduce(h, g.data_ptr(), g.numel(), _lib.OD_DT_F32, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert torch.equal(g, ref)
+    _lib.check(ctx.lib.od_comm_destroy(h))

@@ -42,3 +42,38 @@ def test_sharded_predict_world2():
     assert all(r[2] for r in res)
     # every image is processed exactly once
     assert sorted(res[0][1] + res[1][1]) == list(range(n))
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from object_detector_amd.trainer import dp_allreduce_, dp_effective_scale, lr_multiplier
+        # each rank holds the loss-scaled gradient sums of ITS shard of the global batch
+        rng = np.random.default_rng(100 + rank)
+        g = torch.from_numpy(rng.normal(0, 1, 1000).astype(np.float32))
+        mine = g.clone()
+        dp_allreduce_(g)
+        q.put((rank, mine.numpy(), g.numpy(), dp_effective_scale(256.0, world), lr_multiplier("b.down1")))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_training_gradient_allreduce_world2():
+    """training's one exchange step: sum of the per-rank gradient buffers, then 1/(loss_scale*world) in the optimizer =
+    the gradient of the mean loss over the global batch (per-rank normalisation)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, port = 2, 29741
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    total = res[0][1] + res[1][1]
+    for r in res:
+        np.testing.assert_allclose(r[2], total, rtol=1e-6)
+        assert r[3] == 1.0 / 512.0 and r[4] == 0.01
+    assert (res[0][2] == res[1][2]).all()  # every rank ends with bit-identical gradients -> identical SGD steps
