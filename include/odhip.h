@@ -210,6 +210,26 @@ int od_allreduce(od_comm* comm, void* buf, long long count, int dtype, void* str
 int od_comm_destroy(od_comm* comm);
 
 /* ------------------------------------------------------------------------------------------------
+ * K14: device-side pixel work of the training generator (reference check_generator.py:17-18; docs/MODEL.md:60-64).
+ * Parameters are sampled on the host; one od_aug_params per output image (device array).  src = packed uint8 RGB source
+ * images (any sizes, located by src_offset/src_h/src_w); out uint8 [B,H,W,3].
+ * crop -> bilinear resize -> flip -> saturation/contrast/brightness -> up to 3 Random-Erasing rectangles.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct od_aug_params {
+  int64_t src_offset;
+  int32_t src_h, src_w;
+  float crop_x1, crop_y1, crop_x2, crop_y2;
+  int32_t flip;
+  float brightness, contrast, saturation;
+  int32_t n_erase;
+  float erase[3][4];
+  uint8_t erase_rgb[3][4];
+} od_aug_params;
+int od_aug_params_bytes(void);
+int od_augment_batch(od_ctx* ctx, const uint8_t* src, const void* params, uint8_t* out, int B, int H, int W,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Native forward plan: the whole layer list of one network executed from C++ (one call per batch, optional
  * hipGraph replay) so Python is not in the per-layer loop.  ops is an array of od_plan_op.
  * ---------------------------------------------------------------------------------------------- */

@@ -32,6 +32,13 @@ class ConvDesc(C.Structure):
     ]
 
 
+class AugParams(C.Structure):
+    _fields_ = [("src_offset", C.c_int64), ("src_h", C.c_int32), ("src_w", C.c_int32),
+                ("crop_x1", C.c_float), ("crop_y1", C.c_float), ("crop_x2", C.c_float), ("crop_y2", C.c_float),
+                ("flip", C.c_int32), ("brightness", C.c_float), ("contrast", C.c_float), ("saturation", C.c_float),
+                ("n_erase", C.c_int32), ("erase", (C.c_float * 4) * 3), ("erase_rgb", (C.c_uint8 * 4) * 3)]
+
+
 class PlanOp(C.Structure):
     _fields_ = [("kind", C.c_int32), ("pad_", C.c_int32), ("conv", ConvDesc)]
 
@@ -100,6 +107,9 @@ _PROTOS = {
     "od_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "od_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
     "od_comm_destroy": (C.c_int, [C.c_void_p]),
+    "od_aug_params_bytes": (C.c_int, []),
+    "od_augment_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p]),
     "od_plan_create": (C.c_int, [C.c_void_p, C.POINTER(PlanOp), C.c_int, C.POINTER(C.c_void_p)]),
     "od_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
     "od_plan_capture": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -105,12 +105,55 @@ def apply_pixels_host(img_u8: np.ndarray, p: AugParams, out_hw) -> np.ndarray:
     return a
 
 
+def apply_pixels_device(images, params, out_hw, device):
+    """K14: list of uint8 [h,w,3] arrays + list[AugParams] -> uint8 torch tensor [B,H,W,3] on `device`."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+    from .net import Context, _stream_ptr
+    ctx = Context.get(device)
+    H, Wd = out_hw
+    B = len(images)
+    arr = (_lib.AugParams * B)()
+    off = 0
+    chunks = []
+    for i, (img, p) in enumerate(zip(images, params)):
+        a = np.ascontiguousarray(img[..., :3], np.uint8)
+        chunks.append(a.reshape(-1))
+        q = arr[i]
+        q.src_offset, q.src_h, q.src_w = off, a.shape[0], a.shape[1]
+        q.crop_x1, q.crop_y1, q.crop_x2, q.crop_y2 = p.crop
+        q.flip, q.brightness, q.contrast, q.saturation = int(p.flip), p.brightness, p.contrast, p.saturation
+        q.n_erase = min(3, len(p.erase))
+        for e, (rect, col) in enumerate(p.erase[:3]):
+            for k in range(4):
+                q.erase[e][k] = rect[k]
+            for k in range(3):
+                q.erase_rgb[e][k] = col[k]
+        off += (a.size + 15) // 16 * 16
+    packed = np.zeros(off, np.uint8)
+    o = 0
+    for c in chunks:
+        packed[o:o + c.size] = c
+        o += (c.size + 15) // 16 * 16
+    dev = torch.device(device)
+    src = torch.from_numpy(packed).to(dev)
+    prm = torch.from_numpy(np.frombuffer(bytes(arr), np.uint8).copy()).to(dev)
+    out = torch.empty((B, H, Wd, 3), dtype=torch.uint8, device=dev)
+    _lib.check(ctx.lib.od_augment_batch(ctx.handle, src.data_ptr(), prm.data_ptr(), out.data_ptr(), B, H, Wd,
+                                        _stream_ptr()), "od_augment_batch")
+    return out
+
+
 class Generator:
-    def __init__(self, input_size, preprocess_input=None, encode_truth=None, random_erasing=True):
+    def __init__(self, input_size, preprocess_input=None, encode_truth=None, random_erasing=True, device=None):
         self.input_size = tuple(int(v) for v in input_size)
         self.preprocess_input = preprocess_input
         self.encode_truth = encode_truth
         self.random_erasing = random_erasing
+        self.device = device  # e.g. "cuda:0": pixel work runs in od_augment_batch (K14); None: host path (PIL)
 
     def _load(self, x):
         if isinstance(x, np.ndarray):
@@ -137,8 +180,17 @@ class Generator:
                 order = rng.permutation(n) if shuffle else np.arange(n)
                 for s in range(0, n, batch_size):
                     idx = order[s:s + batch_size]
-                    imgs, anns = zip(*(self.generate(X[i], y[i], rng, data_augmentation) for i in idx))
-                    xb = np.stack(imgs)
+                    if self.device is not None:
+                        raw = [self._load(X[i]) for i in idx]
+                        prm = [sample_params(rng, y[i], self.random_erasing) if data_augmentation else AugParams()
+                               for i in idx]
+                        xb = apply_pixels_device(raw, prm, self.input_size, self.device).cpu().numpy()
+                        anns = [ObjectsAnnotation(y[i].path, self.input_size[1], self.input_size[0], y[i].classes,
+                                                  transform_boxes(y[i].bboxes, p), y[i].difficults)
+                                for i, p in zip(idx, prm)]
+                    else:
+                        imgs, anns = zip(*(self.generate(X[i], y[i], rng, data_augmentation) for i in idx))
+                        xb = np.stack(imgs)
                     if self.preprocess_input is not None:
                         xb = self.preprocess_input(xb)
                     yb = self.encode_truth(list(anns)) if self.encode_truth is not None else list(anns)

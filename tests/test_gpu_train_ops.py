@@ -89,3 +89,47 @@ def test_loss_no_positives(cuda):
     rl, rg = oloss.loss_and_grad(pred.cpu().numpy(), y.cpu().numpy())
     np.testing.assert_allclose(losses.cpu().numpy(), rl, rtol=2e-5)
     np.testing.assert_allclose(grad.cpu().numpy(), rg, rtol=1e-4, atol=1e-8)
+
+
+def test_augment_batch_bit_exact(cuda):
+    """K14 vs oracle/augment.py: bit-exact uint8 output for crop/flip/colour/erase on ragged source sizes."""
+    from object_detector_amd import od_gen
+    from oracle import augment as oaug
+    rng = np.random.default_rng(12)
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in [(375, 500), (96, 64), (33, 47), (512, 512)]]
+    prm = []
+    for i in range(4):
+        p = od_gen.AugParams()
+        if i != 3:
+            p.crop = (0.05 * i, 0.1, 0.9, 1.0 - 0.07 * i)
+            p.flip = bool(i % 2)
+            p.brightness, p.contrast, p.saturation = 10.0 * i - 12, 0.8 + 0.2 * i, 1.3 - 0.25 * i
+            p.erase = [((0.1, 0.2, 0.4, 0.5), (1, 2, 3)), ((0.5, 0.5, 0.95, 0.9), (200, 100, 50))][:i + 1]
+        prm.append(p)
+    out = od_gen.apply_pixels_device(imgs, prm, (128, 160), cuda).cpu().numpy()
+    for i in range(4):
+        ref = oaug.augment(imgs[i], (128, 160), prm[i].crop, prm[i].flip, prm[i].brightness, prm[i].contrast,
+                           prm[i].saturation, prm[i].erase)
+        assert (out[i] == ref).all(), (i, np.abs(out[i].astype(int) - ref.astype(int)).max())
+    # identity parameters on a same-size image reproduce the image
+    same = od_gen.apply_pixels_device([imgs[3]], [od_gen.AugParams()], (512, 512), cuda).cpu().numpy()[0]
+    assert (same == imgs[3]).all()
+
+
+def test_generator_device_path(cuda, tmp_path):
+    """reference check_assign.py:19-27 flow with the device generator + device encode_truth"""
+    from object_detector_amd import od_gen
+    from object_detector_amd.pb import ObjectsAnnotation, PriorBoxes
+    rng = np.random.default_rng(0)
+    X = np.array([rng.integers(0, 256, (120, 200, 3), dtype=np.uint8) for _ in range(3)], dtype=object)
+    y = np.array([ObjectsAnnotation(None, 200, 120, [i], [[0.2, 0.2, 0.7, 0.8]]) for i in range(3)], dtype=object)
+    pb = PriorBoxes((128, 128), 20, device=cuda)
+    gen = od_gen.create_generator((128, 128), preprocess_input=lambda x: x, encode_truth=pb.encode_truth, device=cuda)
+    g, steps = gen.flow(X, y, batch_size=2, data_augmentation=True, seed=1)
+    assert steps == 2
+    for _i, (xb, yb) in zip(range(3), g):
+        assert xb.dtype == np.uint8 and xb.shape[1:] == (128, 128, 3)
+        assert yb.shape[1:] == (len(pb), 26)
+        for yy in yb:
+            obj = yy[:, 1] == 1
+            assert obj.sum() >= 1 and (np.argmax(yy[obj, 2:-4], -1) < 3).all()

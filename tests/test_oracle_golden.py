@@ -123,3 +123,13 @@ def test_decode_zero_is_prior_and_encode_roundtrip():
     pos = a >= 0
     assert pos.sum() >= 1 and (y[pos, 1] == 1).all() and (y[pos, 2 + 1] == 1).all() and (y[~pos, 1] == 0).all()
     np.testing.assert_allclose(opp.decode_locs(y[:, -4:], pr)[pos], np.repeat(gt, pos.sum(), 0), atol=2e-6)
+
+
+def test_augment_oracle_identity_and_boxes():
+    from oracle import augment as oaug
+    img = np.random.default_rng(0).integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    assert (oaug.augment(img, (40, 56)) == img).all()
+    flipped = oaug.augment(img, (40, 56), flip=True)
+    assert (flipped == img[:, ::-1]).all()
+    er = oaug.augment(img, (40, 56), erase=[((0.25, 0.5, 0.75, 1.0), (9, 8, 7))])
+    assert (er[20:, 14:42] == np.array([9, 8, 7], np.uint8)).all() and (er[:20] == img[:20]).all()
