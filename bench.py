@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="train = BASELINE.json configs[3]/[4]: full training step, batch 32 (320) / 16 (640) per GPU")
     return ap.parse_args()
 
 
@@ -71,6 +73,65 @@ def cpu_baseline(size, seconds):
                       f"same Darknet53+neck+head + numpy decode/top-k/NMS (CPU restatement, not the reference)"}
 
 
+def train_bench(a, rank, world, dev):
+    """One step = prior-box assignment + forward (BN training mode) + loss + backward + gradient all-reduce (RCCL) + SGD."""
+    from object_detector_amd import weights as W
+    from object_detector_amd.net import Context
+    from object_detector_amd.pb import ObjectsAnnotation
+    from object_detector_amd.trainer import Trainer, init_comm
+    size = a.size
+    batch = a.batch or (32 if size <= 320 else 16)
+    comm = None
+    if world > 1:
+        comm, _ = init_comm(Context.get(dev))
+    tr = Trainer(W.random_init(2), batch, (size, size), device=dev, lr=1e-3, momentum=0.9, loss_scale=1024.0, comm=comm,
+                 world_size=world)
+    rng = np.random.default_rng(1000 + rank)
+    x = torch.from_numpy(rng.integers(0, 256, (batch, size, size, 3), dtype=np.uint8)).to(dev)
+    anns = []
+    for _ in range(batch):
+        n = int(np.clip(1 + rng.poisson(1.5), 1, 10))
+        c = rng.uniform(0, 1, (n, 2))
+        wh = np.exp(rng.uniform(np.log(0.05), np.log(0.9), (n, 2)))
+        anns.append(ObjectsAnnotation(None, size, size, rng.integers(0, 20, n),
+                                      np.clip(np.concatenate([c - wh / 2, c + wh / 2], 1), 0, 1).astype(np.float32)))
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        tr.step(x, anns)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.step(x, anns)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    losses = tr.losses.cpu().numpy()
+    if rank == 0:
+        flops_img = 3.0 * (29.01e9 + 7.2e9) * (size / 320.0) ** 2  # fwd + bwd-data + bwd-weight
+        print(json.dumps({
+            "metric": "train_images_per_sec", "value": round(world * batch * a.steps / elapsed, 2), "unit": "images/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"Darknet53 {size}x{size} training step (assign + fwd + focal/CE/smooth-L1 + bwd + "
+                                   f"RCCL all-reduce + SGD), batch {batch} per GPU, synthetic data",
+                       "global_batch": world * batch, "input_size": size, "parallelism": f"dp{world}",
+                       "loss_total": float(losses[3])},
+            "roofline": {"bound": "mfma", "achieved": round(flops_img * world * batch * a.steps / elapsed / 1e12 / world, 2),
+                         "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(flops_img * batch * a.steps / elapsed / 1e12 / PEAK_F16_TFLOPS, 4),
+                         "note": "whole-step algorithmic conv flops / step time (not a single kernel)", "traffic": None}}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -83,6 +144,9 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group("nccl", device_id=dev)
+
+    if a.mode == "train":
+        return train_bench(a, rank, world, dev)
 
     from object_detector_amd.detector import ObjectDetector
     size = a.size

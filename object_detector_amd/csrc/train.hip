@@ -16,7 +16,18 @@
 
 namespace {
 
-constexpr int RED_ROWS = 512;  // rows per workgroup in the channel reductions
+constexpr int RED_ROWS_MAX = 8192;  // rows per workgroup in the channel reductions (upper bound)
+
+// rows per workgroup: enough workgroups to fill the chip (>= ~2048), a multiple of the row lanes of one workgroup
+static inline int rows_per_wg(long long M, int C) {
+  const int G = C >> 3;
+  const int lanes = 256 / (G < 256 ? G : 256);
+  long long r = (M + 1023) / 1024;  // <= ~1024 partial rows for the final pass
+  r = (r + lanes - 1) / lanes * lanes;
+  if (r < lanes) r = lanes;
+  if (r > RED_ROWS_MAX) r = RED_ROWS_MAX;
+  return (int)r;
+}
 
 __device__ __forceinline__ float act_fwd(float a, int act, float alpha) {
   if (act == OD_ACT_LEAKY) return a > 0.f ? a : a * alpha;
@@ -35,14 +46,14 @@ template <int MODE>
 __global__ __launch_bounds__(256) void od_chan_reduce(const f16* __restrict__ z, const f16* __restrict__ dy,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                      long long M, int C, int act, float alpha,
+                                                      long long M, int C, int act, float alpha, int rows_wg,
                                                       float* __restrict__ partials) {
   extern __shared__ float red[];  // [2][256][8]
   const int G = C >> 3;                       // channel groups
   const int tid = threadIdx.x;
   const int lanes = 256 / min(G, 256);        // row lanes per group inside one pass
-  const long long r0 = (long long)blockIdx.x * RED_ROWS;
-  const long long r1 = min(r0 + RED_ROWS, M);
+  const long long r0 = (long long)blockIdx.x * rows_wg;
+  const long long r1 = min(r0 + rows_wg, M);
   for (int g0 = 0; g0 < G; g0 += 256) {       // C > 2048 loops (not used by this network)
     const int g = g0 + (lanes > 1 ? tid % G : tid);
     const int rl = lanes > 1 ? tid / G : 0;
@@ -119,12 +130,27 @@ __global__ __launch_bounds__(256) void od_chan_final(const float* __restrict__ p
                                                      float* __restrict__ o1, float* __restrict__ o2,
                                                      float* __restrict__ o3, float* __restrict__ run_mean,
                                                      float* __restrict__ run_var, float momentum) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  // 8 channels per workgroup x 32 partial lanes; fixed summation order (lane-strided partials, then lanes 0..31)
+  __shared__ float red[2][32][8];
+  const int cl = threadIdx.x & 7, ln = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
   float a = 0.f, b = 0.f;
-  for (int i = 0; i < nblocks; ++i) {
-    a += partials[(long long)i * 2 * C + c];
-    b += partials[(long long)i * 2 * C + C + c];
+  if (c < C) {
+    for (int i = ln; i < nblocks; i += 32) {
+      a += partials[(long long)i * 2 * C + c];
+      b += partials[(long long)i * 2 * C + C + c];
+    }
+  }
+  red[0][ln][cl] = a;
+  red[1][ln][cl] = b;
+  __syncthreads();
+  if (ln != 0 || c >= C) return;
+  a = 0.f;
+  b = 0.f;
+#pragma unroll
+  for (int l = 0; l < 32; ++l) {
+    a += red[0][l][cl];
+    b += red[1][l][cl];
   }
   if (MODE == 0) {
     const float mu = a * invM;
@@ -147,34 +173,46 @@ __global__ __launch_bounds__(256) void od_chan_final(const float* __restrict__ p
   }
 }
 
+// Elementwise passes over [M, C]: thread = (fixed 8-channel group g, row lane); the per-channel constants are loaded
+// once into registers and the thread walks rows -- a grid-stride loop would re-load 8 x (2..6) floats per 16 B of data.
 __global__ __launch_bounds__(256) void od_scale_act_k(const f16* __restrict__ z, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, const f16* __restrict__ res,
-                                                      f16* __restrict__ y, long long nvec, int C8, int act, float alpha,
-                                                      int res_up2, int H, int W) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
-    const int g = (int)(i % C8);
-    const f16x8 zv = *(const f16x8*)(z + i * 8);
+                                                      f16* __restrict__ y, long long M, int C, int act, float alpha,
+                                                      int res_up2, int H, int W, int rows_wg) {
+  const int G = C >> 3, tid = threadIdx.x;
+  const int lanes = 256 / min(G, 256);
+  const int g = lanes > 1 ? tid % G : tid, rl = lanes > 1 ? tid / G : 0;
+  if (g >= G || rl >= lanes) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = scale[g * 8 + e];
+    sh[e] = shift[g * 8 + e];
+  }
+  const long long r0 = (long long)blockIdx.x * rows_wg, r1 = min(r0 + rows_wg, M);
+  for (long long r = r0 + rl; r < r1; r += lanes) {
+    const f16x8 zv = *(const f16x8*)(z + r * C + g * 8);
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = act_fwd((float)zv[e] * scale[g * 8 + e] + shift[g * 8 + e], act, alpha);
+    for (int e = 0; e < 8; ++e) v[e] = act_fwd((float)zv[e] * sc[e] + sh[e], act, alpha);
     if (res) {
-      long long ri = i;
+      long long rr = r;
       if (res_up2) {
-        long long pix = i / C8;
+        long long pix = r;
         const int x = (int)(pix % W);
         pix /= W;
         const int yy = (int)(pix % H);
         const long long b = pix / H;
-        ri = ((b * (H >> 1) + (yy >> 1)) * (W >> 1) + (x >> 1)) * C8 + g;
+        rr = (b * (H >> 1) + (yy >> 1)) * (W >> 1) + (x >> 1);
       }
-      const f16x8 rv = *(const f16x8*)(res + ri * 8);
+      const f16x8 rv = *(const f16x8*)(res + rr * C + g * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
     }
     f16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
-    *(f16x8*)(y + i * 8) = o;
+    *(f16x8*)(y + r * C + g * 8) = o;
   }
 }
 
@@ -183,26 +221,37 @@ __global__ __launch_bounds__(256) void od_bn_bwd_apply_k(const f16* __restrict__
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ sum_dax, const float* __restrict__ sum_da,
-                                                         f16* __restrict__ dz, long long nvec, int C8, float invM, int act,
-                                                         float alpha, int bn) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
-    const int g = (int)(i % C8);
-    const f16x8 zv = *(const f16x8*)(z + i * 8);
-    const f16x8 dv = *(const f16x8*)(dy + i * 8);
+                                                         f16* __restrict__ dz, long long M, int C, float invM, int act,
+                                                         float alpha, int bn, int rows_wg) {
+  const int G = C >> 3, tid = threadIdx.x;
+  const int lanes = 256 / min(G, 256);
+  const int g = lanes > 1 ? tid % G : tid, rl = lanes > 1 ? tid / G : 0;
+  if (g >= G || rl >= lanes) return;
+  float sc[8], sh[8], mu[8], rs[8], k1[8], k2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = g * 8 + e;
+    sc[e] = scale[c];
+    sh[e] = shift[c];
+    mu[e] = bn ? mean[c] : 0.f;
+    rs[e] = bn ? rstd[c] : 0.f;
+    k1[e] = bn ? sum_da[c] * invM : 0.f;
+    k2[e] = bn ? sum_dax[c] * invM : 0.f;
+  }
+  const long long r0 = (long long)blockIdx.x * rows_wg, r1 = min(r0 + rows_wg, M);
+  for (long long r = r0 + rl; r < r1; r += lanes) {
+    const f16x8 zv = *(const f16x8*)(z + r * C + g * 8);
+    const f16x8 dv = *(const f16x8*)(dy + r * C + g * 8);
     f16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int c = g * 8 + e;
       const float zf = (float)zv[e];
-      const float da = (float)dv[e] * act_grad(zf * scale[c] + shift[c], act, alpha);
-      float r = da;
-      if (bn) {
-        const float xh = (zf - mean[c]) * rstd[c];
-        r = scale[c] * (da - sum_da[c] * invM - xh * sum_dax[c] * invM);  // scale = gamma*rstd
-      }
-      o[e] = (f16)r;
+      const float da = (float)dv[e] * act_grad(zf * sc[e] + sh[e], act, alpha);
+      float rr = da;
+      if (bn) rr = sc[e] * (da - k1[e] - ((zf - mu[e]) * rs[e]) * k2[e]);  // scale = gamma*rstd
+      o[e] = (f16)rr;
     }
-    *(f16x8*)(dz + i * 8) = o;
+    *(f16x8*)(dz + r * C + g * 8) = o;
   }
 }
 
@@ -297,8 +346,9 @@ unsigned grid_for(long long nvec) {
 }  // namespace
 
 extern "C" size_t od_bn_workspace_bytes(long long M, int C) {
-  if (M <= 0 || C <= 0) return 0;
-  return (size_t)((M + RED_ROWS - 1) / RED_ROWS) * 2 * C * sizeof(float);
+  if (M <= 0 || C <= 0 || C % 8) return 0;
+  const int rw = rows_per_wg(M, C);
+  return (size_t)((M + rw - 1) / rw) * 2 * C * sizeof(float);
 }
 
 extern "C" int od_bn_stats(od_ctx* ctx, const void* z, long long M, int C, const float* gamma, const float* beta,
@@ -306,7 +356,8 @@ extern "C" int od_bn_stats(od_ctx* ctx, const void* z, long long M, int C, const
                            float* run_var, float momentum, void* workspace, size_t workspace_bytes, void* stream) {
   OD_REQUIRE(ctx && z && gamma && beta && mean && rstd && scale && shift && workspace, "od_bn_stats: null argument");
   OD_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "od_bn_stats: C must be a multiple of 8, <= 2048");
-  const int nblocks = (int)((M + RED_ROWS - 1) / RED_ROWS);
+  const int rw = rows_per_wg(M, C);
+  const int nblocks = (int)((M + rw - 1) / rw);
   if (workspace_bytes < od_bn_workspace_bytes(M, C)) {
     od_set_error("od_bn_stats: workspace too small");
     return OD_ERR_WORKSPACE;
@@ -314,9 +365,9 @@ extern "C" int od_bn_stats(od_ctx* ctx, const void* z, long long M, int C, const
   hipStream_t s = (hipStream_t)stream;
   float* part = (float*)workspace;
   hipLaunchKernelGGL(od_chan_reduce<0>, dim3(nblocks), dim3(256), 2 * 256 * 8 * sizeof(float), s, (const f16*)z,
-                     (const f16*)nullptr, nullptr, nullptr, nullptr, nullptr, M, C, 0, 0.f, part);
+                     (const f16*)nullptr, nullptr, nullptr, nullptr, nullptr, M, C, 0, 0.f, rw, part);
   OD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(od_chan_final<0>, dim3(od_ceil_div(C, 256)), dim3(256), 0, s, part, nblocks, C, 1.f / (float)M, eps,
+  hipLaunchKernelGGL(od_chan_final<0>, dim3(od_ceil_div(C, 8)), dim3(256), 0, s, part, nblocks, C, 1.f / (float)M, eps,
                      gamma, beta, mean, rstd, scale, shift, run_mean, run_var, momentum);
   OD_CHECK_LAUNCH();
   return OD_OK;
@@ -327,10 +378,12 @@ extern "C" int od_scale_act(od_ctx* ctx, const void* z, const float* scale, cons
   OD_REQUIRE(ctx && z && scale && shift && y, "od_scale_act: null argument");
   OD_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "od_scale_act: bad dims");
   OD_REQUIRE(res_mode == OD_RES_NONE || res, "od_scale_act: res_mode set but res is null");
-  const long long nvec = (long long)B * H * W * (C / 8);
-  hipLaunchKernelGGL(od_scale_act_k, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const f16*)z, scale, shift,
-                     res_mode == OD_RES_NONE ? (const f16*)nullptr : (const f16*)res, (f16*)y, nvec, C / 8, act, alpha,
-                     res_mode == OD_RES_UP2, H, W);
+  OD_REQUIRE(C <= 2048, "od_scale_act: C <= 2048");
+  const long long M = (long long)B * H * W;
+  const int rw = rows_per_wg(M, C);
+  hipLaunchKernelGGL(od_scale_act_k, dim3((unsigned)((M + rw - 1) / rw)), dim3(256), 0, (hipStream_t)stream, (const f16*)z,
+                     scale, shift, res_mode == OD_RES_NONE ? (const f16*)nullptr : (const f16*)res, (f16*)y, M, C, act,
+                     alpha, res_mode == OD_RES_UP2, H, W, rw);
   OD_CHECK_LAUNCH();
   return OD_OK;
 }
@@ -341,7 +394,8 @@ extern "C" int od_bn_bwd(od_ctx* ctx, const void* z, const void* dy, const float
   OD_REQUIRE(ctx && z && dy && scale && shift && dz && dgamma && dbeta && workspace, "od_bn_bwd: null argument");
   OD_REQUIRE(!bn || (mean && rstd), "od_bn_bwd: bn needs mean/rstd");
   OD_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "od_bn_bwd: C must be a multiple of 8, <= 2048");
-  const int nblocks = (int)((M + RED_ROWS - 1) / RED_ROWS);
+  const int rw = rows_per_wg(M, C);
+  const int nblocks = (int)((M + rw - 1) / rw);
   const size_t need = od_bn_workspace_bytes(M, C) + 2 * (size_t)C * sizeof(float);
   if (workspace_bytes < need) {
     od_set_error("od_bn_bwd: workspace %zu < %zu", workspace_bytes, need);
@@ -352,16 +406,15 @@ extern "C" int od_bn_bwd(od_ctx* ctx, const void* z, const void* dy, const float
   float* sums = part + (size_t)nblocks * 2 * C;  // [2][C]: this call's sum(da*xhat), sum(da)
   // without BN the "mean/rstd" are not used by the sums we need (dbeta only); pass scale/shift twice to keep pointers valid
   hipLaunchKernelGGL(od_chan_reduce<1>, dim3(nblocks), dim3(256), 2 * 256 * 8 * sizeof(float), s, (const f16*)z,
-                     (const f16*)dy, scale, shift, bn ? mean : shift, bn ? rstd : scale, M, C, act, alpha, part);
+                     (const f16*)dy, scale, shift, bn ? mean : shift, bn ? rstd : scale, M, C, act, alpha, rw, part);
   OD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(od_chan_final<1>, dim3(od_ceil_div(C, 256)), dim3(256), 0, s, part, nblocks, C, 0.f, 0.f,
+  hipLaunchKernelGGL(od_chan_final<1>, dim3(od_ceil_div(C, 8)), dim3(256), 0, s, part, nblocks, C, 0.f, 0.f,
                      (const float*)nullptr, (const float*)nullptr, dgamma, dbeta, sums, sums + C, (float*)nullptr,
                      (float*)nullptr, 0.f);
   OD_CHECK_LAUNCH();
-  const long long nvec = M * (C / 8);
-  hipLaunchKernelGGL(od_bn_bwd_apply_k, dim3(grid_for(nvec)), dim3(256), 0, s, (const f16*)z, (const f16*)dy, scale,
-                     shift, bn ? mean : shift, bn ? rstd : scale, sums, sums + C, (f16*)dz, nvec, C / 8, 1.f / (float)M,
-                     act, alpha, bn);
+  hipLaunchKernelGGL(od_bn_bwd_apply_k, dim3(nblocks), dim3(256), 0, s, (const f16*)z, (const f16*)dy, scale, shift,
+                     bn ? mean : shift, bn ? rstd : scale, sums, sums + C, (f16*)dz, M, C, 1.f / (float)M, act, alpha, bn,
+                     rw);
   OD_CHECK_LAUNCH();
   return OD_OK;
 }
