@@ -124,8 +124,24 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), MINW) void od_conv_ig
   // loader state: the NEXT step to stage (steps are staged strictly in order) -- all wave-uniform scalars
   int ld_k0 = 0, ld_c0 = 0, ld_tap = 0, ld_tapoff = 0, ld_dx = 0, ld_dy = 0;
 
+  // SPEC == 2: the loader waves stage through REGISTERS (global_load_dwordx4 -> ds_write_b128) instead of LDS-DMA: the
+  // L2 -> LDS-DMA path tops out near 30 B/clk/CU, plain vector loads from L2 reach about twice that
+  constexpr int NX = AR + BR;
+  f16x8 rtmp[SPEC == 2 ? NX : 1];
+  char* rdst[SPEC == 2 ? NX : 1];
+  int rn = 0;
+  auto xfer = [&](const f16* src, char* lds_piece) {
+    if (SPEC == 2) {
+      rtmp[rn] = *(const f16x8*)src;
+      rdst[rn] = lds_piece + lane * 16;
+      ++rn;
+    } else {
+      glds16(src, lds_piece);
+    }
+  };
   auto stage = [&](int buf) {
     if (p.dbg & 1) return;
+    rn = 0;
     char* abuf = smem + buf * Cf::STAGE_BYTES + piece_off;
     char* bbuf = abuf + Cf::A_BYTES;
     if (UNI) {
@@ -141,7 +157,7 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), MINW) void od_conv_ig
         } else {
           src = ok ? p.x + (a_base[rd] + koff) : p.zero;
         }
-        glds16(src, abuf + rd * RPR * ROWB);
+        xfer(src, abuf + rd * RPR * ROWB);
       }
     } else {
       const int k = ld_k0 + lc * 8;
@@ -155,11 +171,15 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), MINW) void od_conv_ig
         const int hi = a_hi0[rd] + dy, wi = a_wi0[rd] + dx;
         const bool ok = kvalid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
         const f16* src = ok ? p.x + (a_base[rd] + koff) : p.zero;
-        glds16(src, abuf + rd * RPR * ROWB);
+        xfer(src, abuf + rd * RPR * ROWB);
       }
     }
 #pragma unroll
-    for (int rd = 0; rd < BR; ++rd) glds16(wrow + (long long)rd * RPR * p.Kstride + ld_k0, bbuf + rd * RPR * ROWB);
+    for (int rd = 0; rd < BR; ++rd) xfer(wrow + (long long)rd * RPR * p.Kstride + ld_k0, bbuf + rd * RPR * ROWB);
+    if (SPEC == 2) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) *(f16x8*)rdst[i] = rtmp[i];
+    }
     // advance to the next step
     ld_k0 += BK;
     if (UNI) {
@@ -204,6 +224,7 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), MINW) void od_conv_ig
     } else {
       wait_vmcnt<0>();
     }
+    if (SPEC == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave's piece of step ks landed; everyone finished reading step ks-1
     {
       const int nxt = ks + STAGES - 1;
@@ -275,6 +296,14 @@ struct TileCfg {
         "od_conv_igemm_spec<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", 1>",                    \
         "od_conv_igemm_spec<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", 3>", ""                 \
   }
+#define OD_CFG_S2(BM, BN, BK, ST, WM, WN, MINW)                                                                     \
+  {                                                                                                                 \
+    BM, BN, BK, WM* WN * 128, (size_t)ConvCfg<BM, BN, BK, ST, WM, WN, 1>::LDS_BYTES,                                \
+        (const void*)&od_conv_igemm<BM, BN, BK, ST, WM, WN, 1, MINW, true, 2>,                                      \
+        (const void*)&od_conv_igemm<BM, BN, BK, ST, WM, WN, 3, MINW, true, 2>, nullptr,                             \
+        "od_conv_igemm_rspec<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", 1>",                   \
+        "od_conv_igemm_rspec<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", 3>", ""                \
+  }
 #define OD_CFG_G(BM, BN, BK, ST, WM, WN, MINW)                                                                      \
   {                                                                                                                 \
     BM, BN, BK, WM* WN * 64, (size_t)ConvCfg<BM, BN, BK, ST, WM, WN>::LDS_BYTES,                                    \
@@ -305,6 +334,9 @@ const TileCfg g_cfgs[] = {
     OD_CFG_S(256, 128, 64, 2, 2, 2, 2),  // 15: MFMA wave tile 128x64, 96 KiB, 1 WG/CU
     OD_CFG_S(256, 128, 64, 3, 2, 2, 2),  // 16: 144 KiB
     OD_CFG_S(64, 128, 64, 2, 2, 2, 4),   // 17: small-M layers
+    OD_CFG_S2(128, 128, 64, 2, 2, 2, 4), // 18: register-staged loaders, 2 WG/CU
+    OD_CFG_S2(64, 128, 64, 2, 2, 2, 4),  // 19
+    OD_CFG_S2(256, 128, 64, 2, 2, 2, 2), // 20: 96 KiB, 1 WG/CU
 };
 constexpr int kNumCfgs = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 

@@ -28,6 +28,9 @@ def _ref(x, w, scale, bias, stride, act, alpha, res=None, up2=False):
     return y
 
 
+NIG, NWIN = 21, 12   # implicit-GEMM tile configs 0..20, LDS-window configs 21..32 (od_conv_num_tile_cfgs == NIG + NWIN)
+SPEC0 = 13            # first wave-specialised implicit-GEMM config
+
 CASES = [
     # B, H, W, Cin, Cout, k, stride, act, res, cfg
     (2, 16, 16, 32, 64, 3, 1, "leaky", "same", -1),     # Cin=32: per-lane tap path, K tail (288 -> 320)
@@ -36,78 +39,23 @@ CASES = [
     (1, 8, 8, 64, 32, 1, 1, "leaky", "none", -1),       # Cout=32 < BN
     (2, 12, 20, 256, 256, 3, 1, "elu", "up2", -1),      # neck lateral-style, non-square
     (2, 10, 10, 512, 1024, 3, 1, "leaky", "same", -1),  # long K
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 0),
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 1),
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 2),
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 3),
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 4),
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 5),
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 6),
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 7),
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 8),
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 9),
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 10),
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 11),
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 12),
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 13),
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 14),
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 15),
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 16),
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 17),
-    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 4),
-    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 5),
-    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 6),
-    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 7),
-    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 8),
-    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 9),
-    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 10),
-    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 11),
-    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 12),
-    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 13),
-    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 14),
-    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 15),
-    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 16),
-    (3, 10, 10, 128, 64, 1, 1, "elu", "none", 17),
-    (2, 10, 10, 512, 256, 3, 1, "leaky", "same", 13),   # wave-specialised igemm, long K
-    (2, 10, 10, 512, 256, 3, 1, "leaky", "same", 14),   # wave-specialised igemm, long K
-    (2, 10, 10, 512, 256, 3, 1, "leaky", "same", 15),   # wave-specialised igemm, long K
-    (2, 10, 10, 512, 256, 3, 1, "leaky", "same", 16),   # wave-specialised igemm, long K
-    (2, 10, 10, 512, 256, 3, 1, "leaky", "same", 17),   # wave-specialised igemm, long K
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 18),    # LDS-window kernels
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 19),    # LDS-window kernels
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 20),    # LDS-window kernels
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 21),    # LDS-window kernels
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 22),    # LDS-window kernels
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 23),    # LDS-window kernels
-    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 18),      # 4 slices, ragged M (300) and N (320)
-    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 19),      # 4 slices, ragged M (300) and N (320)
-    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 20),      # 4 slices, ragged M (300) and N (320)
-    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 21),      # 4 slices, ragged M (300) and N (320)
-    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 22),      # 4 slices, ragged M (300) and N (320)
-    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 23),      # 4 slices, ragged M (300) and N (320)
-    (1, 40, 40, 128, 256, 3, 1, "leaky", "same", 18),   # W=40: window spans 2W+2 extra pixels
-    (2, 20, 20, 512, 128, 3, 1, "leaky", "up2", 21),    # 8 slices
-    (1, 3, 5, 64, 64, 3, 1, None, "none", 19),          # map smaller than a tile: every edge case at once
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 24),    # specialised LDS-window kernels
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 25),    # specialised LDS-window kernels
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 26),    # specialised LDS-window kernels
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 27),    # specialised LDS-window kernels
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 28),    # specialised LDS-window kernels
-    (2, 12, 12, 64, 128, 3, 1, "leaky", "same", 29),    # specialised LDS-window kernels
-    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 24),      # slice changes (window reload / streaming)
-    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 25),      # slice changes (window reload / streaming)
-    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 26),      # slice changes (window reload / streaming)
-    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 27),      # slice changes (window reload / streaming)
-    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 28),      # slice changes (window reload / streaming)
-    (3, 10, 10, 256, 320, 3, 1, "elu", "none", 29),      # slice changes (window reload / streaming)
-    (1, 40, 40, 128, 256, 3, 1, "leaky", "same", 24),
-    (1, 40, 40, 128, 256, 3, 1, "leaky", "same", 26),
-    (1, 40, 40, 128, 256, 3, 1, "leaky", "same", 28),
-    (2, 16, 16, 32, 64, 3, 2, "leaky", "none", 5),       # Cin=32 is tap-uniform at BK=32
-    (2, 9, 9, 40, 72, 1, 1, "leaky", "none", 5),          # 1x1 channel tail (Cin=40) masked per lane
-    (1, 6, 6, 24, 16, 3, 1, "leaky", "none", 3),          # generic 3x3 (Cin=24) on a legacy config
-    (1, 4, 4, 8, 8, 3, 1, None, "none", -1),             # tiny everything: Cin=8, single partial tile
+    (1, 4, 4, 8, 8, 3, 1, None, "none", -1),            # tiny everything: Cin=8, single partial tile
+    (2, 16, 16, 32, 64, 3, 2, "leaky", "none", 5),      # Cin=32 is tap-uniform at BK=32
+    (2, 9, 9, 40, 72, 1, 1, "leaky", "none", 5),        # 1x1 channel tail (Cin=40) masked per lane
+    (1, 6, 6, 24, 16, 3, 1, "leaky", "none", 3),        # generic 3x3 (Cin=24) on a legacy config
 ]
+CASES += [(2, 12, 12, 64, 128, 3, 1, "leaky", "same", c) for c in range(NIG + NWIN)]          # every config
+CASES += [(3, 10, 10, 128, 64, 1, 1, "elu", "none", c) for c in range(4, NIG)]                 # 1x1 on every igemm config
+CASES += [(2, 10, 10, 512, 256, 3, 1, "leaky", "same", c) for c in range(SPEC0, NIG)]          # specialised, long K
+CASES += [(3, 10, 10, 256, 320, 3, 1, "elu", "none", c) for c in range(NIG, NIG + NWIN)]      # window: slice changes, ragged M/N
+CASES += [(1, 40, 40, 128, 256, 3, 1, "leaky", "same", c) for c in (NIG, NIG + 6, NIG + 8, NIG + 10)]  # W = 40
+CASES += [(2, 20, 20, 512, 128, 3, 1, "leaky", "up2", NIG + 3),                                 # 8 slices
+          (1, 3, 5, 64, 64, 3, 1, None, "none", NIG + 1)]                                       # map smaller than a tile
+
+
+def test_config_table_size(cuda):
+    from object_detector_amd import _lib
+    assert _lib.load().od_conv_num_tile_cfgs() == NIG + NWIN
 
 
 @pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
