@@ -196,6 +196,20 @@ def main():
     g = groups[dom]
     achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
     net_ms = float(ms.sum())
+    # HBM-side bytes per launch of that kernel from the committed PMC passes (profiles/, rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE with the gfx950 x2 FETCH correction); PMC cannot be collected from inside this process -> null if absent
+    traffic = None
+    try:
+        import pathlib
+        pj = pathlib.Path(__file__).resolve().parent / "profiles" / "r01" / "pmc_traffic.json"
+        if size == 320 and batch == 32 and pj.exists():
+            for kname, rec in json.loads(pj.read_text())["kernels"].items():
+                if dom in kname:
+                    traffic = {"hbm_bytes_per_launch": rec["hbm_bytes_per_launch"],
+                               "algorithmic_bytes_per_launch": round(g["bytes"] / g["n"]),
+                               "source": "profiles/r01/pmc_traffic.json"}
+    except Exception:
+        traffic = None
     if a.layers and rank == 0:
         for t, nm, inf in zip(ms, names, info):
             tf = inf["flops"] / (t * 1e-3) / 1e12
@@ -234,7 +248,7 @@ def main():
                          "algorithmic_gflop_per_launch": round(g["flops"] / g["n"] / 1e9, 3),
                          "network_ms_per_batch": round(net_ms, 4),
                          "network_tflops": round(sum(i["flops"] for i in info) / (net_ms * 1e-3) / 1e12, 2),
-                         "traffic": None},
+                         "traffic": traffic},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(size, a.cpu_seconds)

@@ -84,6 +84,9 @@ typedef struct od_conv_desc {
   int32_t tile_cfg; /* -1 = auto; otherwise index into the tile-config table (od_conv_num_tile_cfgs) */
   int32_t transposed; /* != 0: backward-data of a 3x3 stride-2 conv: x is [B,H,W,Cin] = dZ, out is [B,2H,2W,Cout];
                          w must be the flipped / channel-swapped pack written by od_pack_weights */
+  int32_t splitk;     /* split-K factor for small-M layers: 0 = library decides, 1 = off; needs splitk_workspace */
+  void* splitk_workspace; /* f32 scratch for the partial slabs [splitk][B*Ho*Wo*Cout] (NULL = never split) */
+  int64_t splitk_workspace_bytes; /* its size; the factor is clamped so that the slabs fit */
 } od_conv_desc;
 
 int od_conv_weight_dims(int cout, int cin, int ksize, int* cout_pad, int* kpad);

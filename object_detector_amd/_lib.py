@@ -28,7 +28,8 @@ class ConvDesc(C.Structure):
         ("ksize", C.c_int32), ("stride", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float),
         ("res_mode", C.c_int32), ("out_dtype", C.c_int32),
         ("out_batch_stride", C.c_int64), ("out_pix_stride", C.c_int64),
-        ("tile_cfg", C.c_int32), ("transposed", C.c_int32),
+        ("tile_cfg", C.c_int32), ("transposed", C.c_int32), ("splitk", C.c_int32),
+        ("splitk_workspace", C.c_void_p), ("splitk_workspace_bytes", C.c_int64),
     ]
 
 

@@ -18,6 +18,8 @@ struct ConvKP {
   int res_mode, out_f32;
   long long obs, ops;
   int mtiles, ntiles;
+  int splitk, steps_per_split;  // split-K (small-M layers): each workgroup reduces a K range, f32 atomics into ws
+  float* ws;                    // [splitk][M][Cout] f32 partial slabs; od_conv_finish sums them and applies the epilogue
   int tconv, Hs, Ws;  // transposed (backward-data of a stride-2 conv): x is [B,Hs,Ws,Cin], gathered through a 2x zero-upsampled view
   int dbg;  // tuning ablations (OD_CONV_DEBUG): bit0 = skip the DMA, bit1 = skip fragment reads + MFMA
 };
@@ -61,7 +63,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvKP& p, char* smem
   // latency overlaps the LDS staging instead of serialising pass after pass
   constexpr int NPASS = WTM / RPP;
   f16x8 resv[WM][NPASS];
-  if (p.res_mode != OD_RES_NONE) {
+  if (p.res_mode != OD_RES_NONE && p.splitk <= 1) {
 #pragma unroll
     for (int wr = 0; wr < WM; ++wr)
 #pragma unroll
@@ -94,6 +96,24 @@ static __device__ __forceinline__ void conv_epilogue(const ConvKP& p, char* smem
       }
     }
     __syncthreads();
+    if (p.splitk > 1) {
+      // split-K: store this workgroup's partial tile into ITS slab of the f32 workspace (plain 16-B stores, no atomics:
+      // od_conv_finish sums the slabs in a fixed order, so the result is bit-reproducible); scale / bias / activation /
+      // residual happen there too
+      float* slab = p.ws + (long long)((int)blockIdx.x % p.splitk) * p.M * p.Cout;
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int row = ps * RPP + tid / CH;
+        const int m = m0 + wr * WTM + row;
+        if (m < p.M && n < p.Cout) {
+          float* o = slab + (long long)m * p.Cout + n;
+          *(f32x4*)o = *(const f32x4*)(stg + row * SLD + c8);
+          *(f32x4*)(o + 4) = *(const f32x4*)(stg + row * SLD + c8 + 4);
+        }
+      }
+      if (wr + 1 < WM) __syncthreads();
+      continue;
+    }
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int row = ps * RPP + tid / CH;

@@ -72,12 +72,17 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), MINW) void od_conv_ig
   int logical;
   {
     const int nt = p.mtiles * p.ntiles;
-    const int pid = blockIdx.x;
+    const int pid = p.splitk > 1 ? (int)blockIdx.x / p.splitk : (int)blockIdx.x;
     const int q = nt >> 3, r = nt & 7, xcd = pid & 7, loc = pid >> 3;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
   const int tm = logical / p.ntiles, tn = logical - tm * p.ntiles;
   const int m0 = tm * BM, n0 = tn * BN;
+  // split-K: this workgroup's K-step range
+  const int nk_all = (p.Ktot + BK - 1) / BK;
+  const int ks0 = p.splitk > 1 ? ((int)blockIdx.x % p.splitk) * p.steps_per_split : 0;
+  const int nk = p.splitk > 1 ? min(p.steps_per_split, nk_all - ks0) : nk_all;
+  if (nk <= 0) return;  // uniform for the whole workgroup
 
   // ---- per-lane gather state --------------------------------------------------------------------------------
   int rr, lc, piece_off;  // row inside a DMA round, logical 16-B chunk fetched, LDS byte offset of this wave's piece
@@ -122,7 +127,14 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), MINW) void od_conv_ig
   const f16* wrow = p.w + (long long)(n0 + rr) * p.Kstride + lc * 8;
 
   // loader state: the NEXT step to stage (steps are staged strictly in order) -- all wave-uniform scalars
-  int ld_k0 = 0, ld_c0 = 0, ld_tap = 0, ld_tapoff = 0, ld_dx = 0, ld_dy = 0;
+  int ld_k0 = ks0 * BK, ld_c0 = ld_k0, ld_tap = 0, ld_tapoff = 0, ld_dx = 0, ld_dy = 0;
+  if (UNI && KS == 3) {
+    ld_tap = ld_k0 / p.Cin;
+    ld_c0 = ld_k0 - ld_tap * p.Cin;
+    ld_dy = ld_tap / 3;
+    ld_dx = ld_tap - ld_dy * 3;
+    ld_tapoff = (ld_dy * p.W + ld_dx) * p.Cin;
+  }
 
   // SPEC == 2: the loader waves stage through REGISTERS (global_load_dwordx4 -> ds_write_b128) instead of LDS-DMA: the
   // L2 -> LDS-DMA path tops out near 30 B/clk/CU, plain vector loads from L2 reach about twice that
@@ -206,7 +218,6 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), MINW) void od_conv_ig
 #pragma unroll
     for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.Ktot + BK - 1) / BK;
   if (is_loader) {
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
@@ -266,6 +277,57 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), MINW) void od_conv_ig
   conv_epilogue<BN, WM, WN, MT, NTL, Cf::NTHREADS>(p, smem, acc, m0, n0, tid_all, is_consumer ? wm : -1, wn, l15, lq);
 }
 
+// split-K finish: out = act(scale * sum_s slab[s] + bias) (+ residual); slabs summed in ascending s (deterministic)
+__global__ __launch_bounds__(256) void od_conv_finish(ConvKP p) {
+  const long long nvec = (long long)p.M * (p.Cout >> 3);
+  const int C8 = p.Cout >> 3;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i / C8), n = (int)(i - (long long)m * C8) * 8;
+    const float* wsp = p.ws + (long long)m * p.Cout + n;
+    const long long slab = (long long)p.M * p.Cout;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int sidx = 0; sidx < p.splitk; ++sidx) {
+      const f32x4 a0 = *(const f32x4*)(wsp + sidx * slab), a1 = *(const f32x4*)(wsp + sidx * slab + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] += a0[e];
+        v[4 + e] += a1[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = v[e] * p.scale[n + e] + p.bias[n + e];
+      if (p.act == OD_ACT_LEAKY) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+      else if (p.act == OD_ACT_ELU) v[e] = v[e] > 0.f ? v[e] : p.alpha * expm1f(v[e]);
+    }
+    const unsigned b = (unsigned)m / (unsigned)p.HoWo;
+    const unsigned pix = (unsigned)m - b * (unsigned)p.HoWo;
+    if (p.res_mode != OD_RES_NONE) {
+      long long roff;
+      if (p.res_mode == OD_RES_SAME) {
+        roff = (long long)m * p.Cout + n;
+      } else {
+        const unsigned ho = pix / (unsigned)p.Wo, wo = pix - ho * (unsigned)p.Wo;
+        roff = ((long long)(b * (unsigned)(p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout + n;
+      }
+      const f16x8 r = *(const f16x8*)(p.res + roff);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+    }
+    const long long ooff = (long long)b * p.obs + (long long)pix * p.ops + n;
+    if (p.out_f32) {
+      float* o = (float*)p.out + ooff;
+      *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
+      *(f32x4*)(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+      f16x8 h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] = (f16)v[e];
+      *(f16x8*)((f16*)p.out + ooff) = h;
+    }
+  }
+}
+
 struct TileCfg {
   int BM, BN, BK, threads;
   size_t lds;
@@ -280,7 +342,7 @@ struct TileCfg {
 #define OD_STR2(x) #x
 #define OD_STR(x) OD_STR2(x)
 #define OD_NAME(BM, BN, BK, ST, WM, WN, KS, MINW, UNI)                                                              \
-  "od_conv_igemm<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", " OD_STR(WM) ", " OD_STR(WN) ", " OD_STR(KS) ", " OD_STR(MINW) ", " #UNI ">"
+  "od_conv_igemm<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", " OD_STR(WM) ", " OD_STR(WN) ", " OD_STR(KS) ", " OD_STR(MINW) ", " #UNI ", 0>"
 #define OD_CFG(BM, BN, BK, ST, WM, WN, MINW)                                                                        \
   {                                                                                                                 \
     BM, BN, BK, WM* WN * 64, (size_t)ConvCfg<BM, BN, BK, ST, WM, WN>::LDS_BYTES,                                    \
@@ -293,16 +355,16 @@ struct TileCfg {
     BM, BN, BK, WM* WN * 128, (size_t)ConvCfg<BM, BN, BK, ST, WM, WN, 1>::LDS_BYTES,                                \
         (const void*)&od_conv_igemm<BM, BN, BK, ST, WM, WN, 1, MINW, true, 1>,                                      \
         (const void*)&od_conv_igemm<BM, BN, BK, ST, WM, WN, 3, MINW, true, 1>, nullptr,                             \
-        "od_conv_igemm_spec<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", 1>",                    \
-        "od_conv_igemm_spec<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", 3>", ""                 \
+        "od_conv_igemm<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", " OD_STR(WM) ", " OD_STR(WN) ", 1, " OD_STR(MINW) ", true, 1>", \
+        "od_conv_igemm<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", " OD_STR(WM) ", " OD_STR(WN) ", 3, " OD_STR(MINW) ", true, 1>", "" \
   }
 #define OD_CFG_S2(BM, BN, BK, ST, WM, WN, MINW)                                                                     \
   {                                                                                                                 \
     BM, BN, BK, WM* WN * 128, (size_t)ConvCfg<BM, BN, BK, ST, WM, WN, 1>::LDS_BYTES,                                \
         (const void*)&od_conv_igemm<BM, BN, BK, ST, WM, WN, 1, MINW, true, 2>,                                      \
         (const void*)&od_conv_igemm<BM, BN, BK, ST, WM, WN, 3, MINW, true, 2>, nullptr,                             \
-        "od_conv_igemm_rspec<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", 1>",                   \
-        "od_conv_igemm_rspec<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", 3>", ""                \
+        "od_conv_igemm<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", " OD_STR(WM) ", " OD_STR(WN) ", 1, " OD_STR(MINW) ", true, 2>", \
+        "od_conv_igemm<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", " OD_STR(WM) ", " OD_STR(WN) ", 3, " OD_STR(MINW) ", true, 2>", "" \
   }
 #define OD_CFG_G(BM, BN, BK, ST, WM, WN, MINW)                                                                      \
   {                                                                                                                 \
@@ -437,7 +499,10 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
     p.dbg = dbg;
   }
   if (use_win) {
-    // LDS-window direct 3x3 (conv_win.hip)
+    // LDS-window direct 3x3 (conv_win.hip); never split-K
+    p.splitk = 1;
+    p.steps_per_split = 0;
+    p.ws = nullptr;
     ConvKernelInfo ki;
     size_t lds = 0;
     OD_REQUIRE(d->ksize == 3, "od_conv2d_fwd: tile_cfg %d is a 3x3 window kernel", cfg);
@@ -463,6 +528,31 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
   }
   p.mtiles = od_ceil_div(M, tc.BM);
   p.ntiles = od_ceil_div(d->Cout, tc.BN);
+  // split-K for layers that cannot fill the chip with output tiles (batch-1 inference): every K-range workgroup writes
+  // its partial tile to its own slab of the caller's f32 workspace; splitk == 0 lets the library choose
+  p.splitk = 1;
+  p.steps_per_split = 0;
+  p.ws = (float*)d->splitk_workspace;
+  if (d->splitk_workspace && d->splitk != 1) {
+    const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
+    const int tiles = p.mtiles * p.ntiles;
+    const int nk = od_ceil_div(p.Ktot, tc.BK);
+    static int thr_mul = -1, tgt_mul = -1;  // tuning knobs (OD_SPLITK="thr,tgt"): split when tiles*thr <= CUs, aim at tgt*CUs/2 workgroups
+    if (thr_mul < 0) {
+      thr_mul = 8;  // measured on MI355X (profiles/r01/splitk_sweep.txt): split only when <= CUs/8 tiles,
+      tgt_mul = 1;  // aiming at ~CUs/2 workgroups
+      const char* e = getenv("OD_SPLITK");
+      if (e) sscanf(e, "%d,%d", &thr_mul, &tgt_mul);
+    }
+    int sk = d->splitk > 1 ? d->splitk : ((tiles * thr_mul <= cus && nk >= 8) ? od_ceil_div(tgt_mul * cus / 2, tiles) : 1);
+    if (sk > nk / 4) sk = nk / 4;  // >= 4 K steps per workgroup
+    const long long slab_bytes = (long long)M * d->Cout * 4;
+    if ((long long)sk * slab_bytes > (long long)d->splitk_workspace_bytes) sk = (int)(d->splitk_workspace_bytes / slab_bytes);
+    if (sk > 1) {
+      p.steps_per_split = od_ceil_div(nk, sk);
+      p.splitk = od_ceil_div(nk, p.steps_per_split);
+    }
+  }
   // weights/scale/bias are padded to a multiple of 256 output channels, so any BN <= 256 tile stays in bounds.
 
   // kernel variant: 1x1 / 3x3-uniform-tap / 3x3-generic (odd channel counts fall back to a config that has one)
@@ -481,7 +571,14 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
     attr_done[cfg][variant] = true;
   }
   void* args[] = {&p};
-  OD_CHECK_HIP(hipLaunchKernel(fn, dim3(p.mtiles * p.ntiles), dim3(tc.threads), args, tc.lds, stream));
+  OD_CHECK_HIP(hipLaunchKernel(fn, dim3(p.mtiles * p.ntiles * p.splitk), dim3(tc.threads), args, tc.lds, stream));
+  if (p.splitk > 1) {
+    const long long nvec = (long long)p.M * (p.Cout / 8);
+    long long fb = (nvec + 255) / 256;
+    if (fb > 2048) fb = 2048;
+    hipLaunchKernelGGL(od_conv_finish, dim3((unsigned)fb), dim3(256), 0, stream, p);
+    OD_CHECK_LAUNCH();
+  }
   return OD_OK;
 }
 

@@ -80,6 +80,9 @@ class Net:
         self.level_hw = [(self.H // s, self.W // s) for s in (8, 16, 32)]
         self.P = sum(h * w for h, w in self.level_hw) * W.NUM_PRIORS
         self.tile_cfg = tile_cfg or {}
+        self.splitk = True  # small-M layers (batch-1) may use split-K through a shared f32 slab workspace
+        self._splitk_elems = 0
+        self._splitk_descs = []
         self._keep = []  # device tensors referenced by raw pointers in the plan
         self._dev = {}
         for name, cin, cout, k, _s, _bn in W.layer_specs(self.num_classes, self.neck_ch, self.tower):
@@ -99,6 +102,13 @@ class Net:
         self.ops = []       # (_lib.PlanOp)
         self.op_info = []   # dict(name, flops, bytes)
         self._build(backbone_act, head_act)
+        if self._splitk_elems:
+            nbytes = min(32 * self._splitk_elems * 4, 256 << 20)  # room for up to 32 partial slabs of the largest layer
+            self.splitk_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            for i in self._splitk_descs:
+                self.ops[i].conv.splitk = 0
+                self.ops[i].conv.splitk_workspace = self.splitk_ws.data_ptr()
+                self.ops[i].conv.splitk_workspace_bytes = nbytes
         arr = (_lib.PlanOp * len(self.ops))(*self.ops)
         h = C.c_void_p()
         _lib.check(self.lib.od_plan_create(self.ctx.handle, arr, len(self.ops), C.byref(h)), "od_plan_create")
@@ -133,11 +143,14 @@ class Net:
         d.out_dtype = _lib.OD_DT_F32 if out_f32 else _lib.OD_DT_F16
         d.out_batch_stride, d.out_pix_stride = obs, ops
         d.tile_cfg = self.tile_cfg.get(name, -1)
+        m = self.B * ho * wo
+        if self.splitk and m * cout <= (1 << 22):  # candidates only; the library decides per layer
+            self._splitk_elems = max(self._splitk_elems, m * cout)
+            self._splitk_descs.append(len(self.ops))
         op = _lib.PlanOp()
         op.kind = _lib.OD_OP_CONV
         op.conv = d
         self.ops.append(op)
-        m = self.B * ho * wo
         osz = 4 if out_f32 else 2
         self.op_info.append(dict(name=name, flops=2.0 * m * cout * k * k * cin,
                                  bytes=float(self.B * h * w * cin * 2 + m * cout * osz + cout * k * k * cin * 2

@@ -19,7 +19,7 @@ def _ctx(t: torch.Tensor) -> Context:
 
 def conv2d(x: torch.Tensor, w_ohwi: np.ndarray, scale: np.ndarray, bias: np.ndarray, stride=1, act=None, alpha=0.0,
            res: torch.Tensor | None = None, res_mode="none", out_f32=False, tile_cfg=-1, out=None,
-           out_batch_stride=0, out_pix_stride=0):
+           out_batch_stride=0, out_pix_stride=0, splitk=1, splitk_ws=None):
     """x f16 [B,H,W,Cin] (device) ; w [Cout,k,k,Cin] host array -> out f16/f32 [B,Ho,Wo,Cout]."""
     ctx = _ctx(x)
     assert x.dtype == torch.float16 and x.is_contiguous()
@@ -42,7 +42,13 @@ def conv2d(x: torch.Tensor, w_ohwi: np.ndarray, scale: np.ndarray, bias: np.ndar
     d.out_dtype = _lib.OD_DT_F32 if out_f32 else _lib.OD_DT_F16
     d.out_batch_stride, d.out_pix_stride = out_batch_stride, out_pix_stride
     d.tile_cfg = tile_cfg
+    if splitk != 1:
+        if splitk_ws is None:
+            splitk_ws = torch.empty(32 * B * Ho * Wo * Cout, dtype=torch.float32, device=x.device)
+        d.splitk, d.splitk_workspace, d.splitk_workspace_bytes = splitk, splitk_ws.data_ptr(), splitk_ws.numel() * 4
     _lib.check(ctx.lib.od_conv2d_fwd(ctx.handle, C.byref(d), _stream_ptr()), "od_conv2d_fwd")
+    if splitk != 1:
+        out._splitk_ws = splitk_ws  # keep the workspace alive / inspectable
     return out
 
 

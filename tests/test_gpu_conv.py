@@ -88,6 +88,46 @@ def test_conv_matches_oracle(cuda, case):
     assert (err <= tol).all(), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
 
 
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, k, stride, act, res, cfg, splitk
+    (1, 10, 10, 512, 1024, 3, 1, "leaky", "same", 13, 0),   # batch-1 stage-5 shape, library-chosen split
+    (1, 10, 10, 512, 1024, 3, 1, "leaky", "same", 0, 6),
+    (1, 20, 20, 512, 256, 1, 1, "elu", "up2", 17, 4),       # 1x1, split over channels
+    (1, 20, 20, 256, 512, 3, 2, "leaky", "none", 2, 0),     # stride 2
+    (1, 10, 10, 256, 208, 3, 1, None, "none", 3, 5),        # ragged Cout, generic-capable config
+    (2, 6, 6, 40, 72, 3, 1, "leaky", "same", 3, 3),         # non-uniform taps (Cin = 40) + split
+], ids=str)
+def test_conv_split_k(cuda, case):
+    """split-K path: per-split f32 slabs + finish kernel summing them in a fixed order (bit-reproducible)."""
+    from object_detector_amd import ops
+    B, H, W, Cin, Cout, k, stride, act, resm, cfg, sk = case
+    rng = np.random.default_rng(11)
+    x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float16)
+    w = (rng.normal(0, 1, (Cout, k, k, Cin)) * np.sqrt(2.0 / (k * k * Cin))).astype(np.float16)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    bias = rng.normal(0, 0.1, Cout).astype(np.float32)
+    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    res = None
+    if resm == "same":
+        res = rng.normal(0, 1, (B, Ho, Wo, Cout)).astype(np.float16)
+    elif resm == "up2":
+        res = rng.normal(0, 1, (B, Ho // 2, Wo // 2, Cout)).astype(np.float16)
+    alpha = 0.1 if act == "leaky" else 1.0
+    rt = torch.from_numpy(res).to(cuda) if res is not None else None
+    out = ops.conv2d(torch.from_numpy(x).to(cuda), w.astype(np.float32), scale, bias, stride=stride, act=act, alpha=alpha,
+                     res=rt, res_mode=resm, tile_cfg=cfg, splitk=sk)
+    out2 = ops.conv2d(torch.from_numpy(x).to(cuda), w.astype(np.float32), scale, bias, stride=stride, act=act,
+                      alpha=alpha, res=rt, res_mode=resm, tile_cfg=cfg, splitk=sk)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)  # deterministic
+    got = out.cpu().numpy().astype(np.float64)
+    ref = _ref(x.astype(np.float32), w.astype(np.float32), scale, bias, stride, act, alpha,
+               None if res is None else res.astype(np.float32), resm == "up2")
+    err = np.abs(got - ref)
+    tol = 1e-3 * max(1.0, np.abs(ref).max()) + 2.0 ** -10 * np.abs(ref)
+    assert (err <= tol).all(), err.max()
+
+
 def test_conv_f32_strided_output(cuda):
     """prediction conv: Cout=208 (not a tile multiple), f32 logits written into a slice of pred[B,P,26]."""
     from object_detector_amd import ops
