@@ -82,8 +82,8 @@ def train_bench(a, rank, world, dev):
     size = a.size
     batch = a.batch or (32 if size <= 320 else 16)
     comm = None
-    if world > 1:
-        comm, _ = init_comm(Context.get(dev))
+    if world > 1 and torch.distributed.get_backend() == "nccl":
+        comm, _ = init_comm(Context.get(dev))  # RCCL communicator through the C ABI (od_comm_*)
     tr = Trainer(W.random_init(2), batch, (size, size), device=dev, lr=1e-3, momentum=0.9, loss_scale=1024.0, comm=comm,
                  world_size=world)
     rng = np.random.default_rng(1000 + rank)
@@ -110,7 +110,8 @@ def train_bench(a, rank, world, dev):
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        nccl = torch.distributed.get_backend() == "nccl"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if nccl else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     losses = tr.losses.cpu().numpy()
@@ -139,11 +140,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != a.gpus and world > 1:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    dev = torch.device(f"cuda:{local_rank}")
+    ndev = max(1, torch.cuda.device_count())
+    dev = torch.device(f"cuda:{local_rank % ndev}")  # one rank per GPU (the modulo only matters for 1-GPU rehearsals)
     torch.cuda.set_device(dev)
+    backend = os.environ.get("OD_BENCH_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; "gloo" to rehearse on one GPU
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
 
     if a.mode == "train":
         return train_bench(a, rank, world, dev)
@@ -172,7 +178,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     keep_count = od.post.keep_count.cpu().numpy()
