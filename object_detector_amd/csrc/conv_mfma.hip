@@ -409,12 +409,14 @@ int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize) {
   if (Cout <= 64) return (ksize == 3 && od_ceil_div(M, 128) >= 8 * cus) ? 1 : 3;
   const long t128 = (long)od_ceil_div(M, 128) * od_ceil_div(Cout, 128);
   if (ksize == 1) {
-    if (!spec_ok) return 3;
-    return M <= 16384 ? 17 : 3;
+    if (!spec_ok || M <= 4096) return 3;
+    if (M <= 16384) return 17;
+    return Cout >= 256 ? 13 : 3;
   }
   if (!spec_ok) return t128 >= 2L * cus ? 0 : 2;
   if (t128 >= cus) return (Cout == 128) ? 2 : 13;  // 4 MFMA waves + 4 DMA waves, 2 workgroups per CU
-  return 14;                                       // few tiles: one deep-ring workgroup per CU
+  if (Cout <= 256) return M <= 4096 ? 3 : 17;      // few, narrow tiles (prediction module on the coarse levels)
+  return 14;                                       // few tiles, long K: one deep-ring workgroup per CU
 }
 
 }  // namespace

@@ -14,7 +14,7 @@ from object_detector_amd import _lib  # noqa: E402
 from object_detector_amd.net import Context, pack_conv_weight  # noqa: E402
 
 
-def run(ctx, B, H, W, Cin, Cout, k, stride, cfg, reps=20, res=True):
+def run(ctx, B, H, W, Cin, Cout, k, stride, cfg, reps=20, res=True, splitk=1):
     dev = torch.device("cuda:0")
     x = torch.randn((B, H, W, Cin), device=dev).half()
     w = np.random.default_rng(0).normal(0, 0.05, (Cout, k, k, Cin)).astype(np.float32)
@@ -29,6 +29,9 @@ def run(ctx, B, H, W, Cin, Cout, k, stride, cfg, reps=20, res=True):
     d.res = r.data_ptr() if res else None
     d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride = B, H, W, Cin, Cout, k, stride
     d.act, d.alpha, d.res_mode, d.out_dtype, d.tile_cfg = 1, 0.1, 1 if res else 0, 0, cfg
+    if splitk != 1:
+        ws = torch.empty(32 * B * Ho * Wo * Cout, dtype=torch.float32, device=dev)
+        d.splitk, d.splitk_workspace, d.splitk_workspace_bytes = splitk, ws.data_ptr(), ws.numel() * 4
     s = torch.cuda.current_stream().cuda_stream
     for _ in range(3):
         _lib.check(ctx.lib.od_conv2d_fwd(ctx.handle, C.byref(d), C.c_void_p(s)))
@@ -50,6 +53,7 @@ def main():
     ap.add_argument("--shapes", default="net")
     ap.add_argument("--cfgs", default="")
     ap.add_argument("--nores", action="store_true")
+    ap.add_argument("--splitk", type=int, default=1)
     a = ap.parse_args()
     ctx = Context.get("cuda:0")
     ncfg = ctx.lib.od_conv_num_tile_cfgs()
@@ -66,13 +70,17 @@ def main():
     big = [("big3x3", 160, 128, 256, 3, 1), ("big1x1", 160, 256, 128, 1, 1)]
     mid = [("mid3x3", 80, 128, 256, 3, 1), ("mid3x3n", 80, 256, 256, 3, 1)]
     w40 = [("w40k2304", 40, 256, 256, 3, 1)]
-    shapes = {"net": net, "big": big, "mid": mid, "w40": w40, "all": net + big}[a.shapes]
+    small = [("n.lat3", S // 8, 256, 256, 1, 1), ("n.lat4", S // 16, 512, 256, 1, 1), ("n.lat5", S // 32, 1024, 256, 1, 1),
+             ("s3.a", S // 8, 256, 128, 1, 1), ("s4.a", S // 16, 512, 256, 1, 1), ("s5.a", S // 32, 1024, 512, 1, 1),
+             ("h.t0.L1", S // 16, 256, 256, 3, 1), ("h.t0.L2", S // 32, 256, 256, 3, 1), ("h.out.L2", S // 32, 256, 208, 3, 1),
+             ("s5.b", S // 32, 512, 1024, 3, 1), ("s4.b", S // 16, 256, 512, 3, 1)]
+    shapes = {"net": net, "big": big, "mid": mid, "w40": w40, "small": small, "all": net + big}[a.shapes]
     print(f"{'layer':8s} {'M':>8s} {'N':>5s} {'K':>5s} | " + " | ".join(f"cfg{c:<2d} us    TF/s" for c in cfgs))
     for name, H, Cin, Cout, k, st in shapes:
         row = []
         for c in cfgs:
             try:
-                us, tf = run(ctx, B, H, H, Cin, Cout, k, st, c, res=(k == 3 and st == 1 and not a.nores))
+                us, tf = run(ctx, B, H, H, Cin, Cout, k, st, c, res=(k == 3 and st == 1 and not a.nores), splitk=a.splitk)
                 row.append(f"{us:8.1f} {tf:7.1f}")
             except _lib.OdError:
                 row.append(f"{'-':>8s} {'-':>7s}")
