@@ -43,8 +43,14 @@ class ObjectsPrediction:
         return len(self.classes)
 
 
-def load_image(x, size_hw, keep_aspect=False):
-    """path / ndarray -> uint8 [H,W,3] resized to the network input (host side: PIL)."""
+def load_image(x, size_hw, keep_aspect=False, return_scale=False):
+    """path / ndarray -> uint8 [H,W,3] resized to the network input (host side: PIL).
+    return_scale: also the (sx, sy) fraction of the canvas the image occupies (1, 1 unless keep_aspect letterboxes)."""
+    out, scale = _load_image(x, size_hw, keep_aspect)
+    return (out, scale) if return_scale else out
+
+
+def _load_image(x, size_hw, keep_aspect):
     from PIL import Image
     H, Wd = size_hw
     if isinstance(x, (str, os.PathLike)):
@@ -54,15 +60,15 @@ def load_image(x, size_hw, keep_aspect=False):
         if a.dtype != np.uint8:
             a = np.clip(a, 0, 255).astype(np.uint8)
         if a.shape[:2] == (H, Wd):
-            return a[..., :3]
+            return a[..., :3], (1.0, 1.0)
         img = Image.fromarray(a[..., :3])
     if not keep_aspect:
-        return np.asarray(img.resize((Wd, H), Image.BILINEAR), np.uint8)
+        return np.asarray(img.resize((Wd, H), Image.BILINEAR), np.uint8), (1.0, 1.0)
     s = min(Wd / img.width, H / img.height)
     nw, nh = max(1, round(img.width * s)), max(1, round(img.height * s))
     canvas = np.zeros((H, Wd, 3), np.uint8)
     canvas[:nh, :nw] = np.asarray(img.resize((nw, nh), Image.BILINEAR), np.uint8)
-    return canvas
+    return canvas, (nw / Wd, nh / H)
 
 
 def dist_info(use_multi_gpu=True):
@@ -140,7 +146,7 @@ class ObjectDetector:
         pred = self.net.forward(x_u8, graph=graph)
         return self.post.run(pred, conf_threshold)
 
-    def _collect(self, n_valid):
+    def _collect(self, n_valid, scales=None):
         keep = self.post.keep_flat[:n_valid].cpu().numpy()
         cnt = self.post.keep_count[:n_valid].cpu().numpy()
         conf = self.post.conf
@@ -152,6 +158,9 @@ class ObjectDetector:
             kt = torch.from_numpy(k).to(self.device)
             confs = conf[b].reshape(-1)[kt].cpu().numpy()
             bxs = boxes[b][kt // NC].cpu().numpy()
+            if scales is not None and scales[b] != (1.0, 1.0):  # keep_aspect: canvas coordinates -> image coordinates
+                sx, sy = scales[b]
+                bxs = np.clip(bxs / np.array([sx, sy, sx, sy], np.float32), 0.0, 1.0)
             out.append(ObjectsPrediction(k % NC, confs, bxs, k))
         return out
 
@@ -165,11 +174,13 @@ class ObjectDetector:
         host = np.zeros((B,) + self.input_size + (3,), np.uint8)
         for s in range(0, len(mine), B):
             idx = mine[s:s + B]
+            scales = []
             for j, i in enumerate(idx):
-                host[j] = load_image(X[i], self.input_size, self.keep_aspect)
+                host[j], sc = load_image(X[i], self.input_size, self.keep_aspect, return_scale=True)
+                scales.append(sc)
             x = torch.from_numpy(host).to(self.device, non_blocking=False)
             self.predict_batch_device(x, conf_threshold)
-            for i, p in zip(idx, self._collect(len(idx))):
+            for i, p in zip(idx, self._collect(len(idx), scales)):
                 results[i] = p
         results = gather_results(results, world)
         return [results[i] for i in range(len(X))]

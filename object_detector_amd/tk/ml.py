@@ -68,6 +68,7 @@ def plot_objects(base_image, classes, confs, bboxes, class_names=None):
     Wd, H = img.size
     for i in range(len(bboxes)):
         x1, y1, x2, y2 = (float(v) for v in bboxes[i])
+        x1, x2, y1, y2 = min(x1, x2), max(x1, x2), min(y1, y2), max(y1, y2)  # an untrained net can decode inverted boxes
         c = int(classes[i]) if classes is not None else 0
         col = tuple(int(v) for v in (np.array([37, 97, 173]) * (c + 1)) % 200 + 55)
         d.rectangle([x1 * Wd, y1 * H, x2 * Wd, y2 * H], outline=col, width=2)

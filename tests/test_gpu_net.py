@@ -81,3 +81,30 @@ def test_predict_end_to_end(cuda):
     # conf_threshold=0.6 (voc_evaluate.py:27) on random weights: nothing (or few) survives, still well-formed
     hi = od.predict(list(x), conf_threshold=0.6)
     assert all(len(p) <= 200 and (p.confs > 0.6).all() for p in hi)
+
+
+def test_entry_points_synthetic(cuda, tmp_path):
+    """scripts/voc_validate.py / voc_evaluate.py / check_assign.py equivalents run end to end (synthetic data + weights)."""
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    for script, extra in (("voc_validate.py", ["--synthetic", "5", "--batch-size", "2", "--input-size", "96", "96"]),
+                          ("voc_evaluate.py", ["--synthetic", "3", "--batch-size", "2", "--input-size", "96", "96"]),
+                          ("check_assign.py", ["--synthetic", "1", "--batches", "2", "--save-dir", str(tmp_path / "assign")])):
+        r = subprocess.run([sys.executable, str(root / "scripts" / script), "--result-dir", str(tmp_path)] + extra
+                           if script.startswith("voc") else [sys.executable, str(root / "scripts" / script)] + extra,
+                           capture_output=True, text=True, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr[-2000:]
+    assert "mAP=" in (tmp_path / "validate.log").read_text()
+    assert len(list((tmp_path / "assign").glob("*.jpg"))) == 2
+
+
+def test_keep_aspect_boxes_map_back(cuda):
+    from object_detector_amd.detector import ObjectDetector, load_image
+    img = np.random.default_rng(0).integers(0, 256, (100, 200, 3), dtype=np.uint8)
+    canvas, (sx, sy) = load_image(img, (96, 96), keep_aspect=True, return_scale=True)
+    assert canvas.shape == (96, 96, 3) and sx == 1.0 and abs(sy - 0.5) < 1e-6 and (canvas[48:] == 0).all()
+    od = ObjectDetector.synthetic(2, (96, 96), keep_aspect=True, device=cuda)
+    p = od.predict([img, img])
+    assert len(p) == 2 and (p[0].bboxes >= 0).all() and (p[0].bboxes <= 1).all()
