@@ -163,4 +163,7 @@ struct ConvKernelInfo {
 
 // conv_win.hip: LDS-window direct 3x3 / stride-1 kernels.  Returns false when the shape cannot use variant `idx`.
 int od_conv_win_num_cfgs();
+// conv_pw.hip: persistent wave-specialised window kernel (one variant)
+bool od_conv_pw_select(const ConvKP& p, int num_cu, ConvKernelInfo* info, size_t* lds_bytes, int* np_out, int* grid,
+                       int* ntiles_total);
 bool od_conv_win_select(int idx, const ConvKP& p, ConvKernelInfo* info, size_t* lds_bytes);

@@ -421,7 +421,7 @@ int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize) {
 
 }  // namespace
 
-extern "C" int od_conv_num_tile_cfgs(void) { return kNumCfgs + od_conv_win_num_cfgs(); }
+extern "C" int od_conv_num_tile_cfgs(void) { return kNumCfgs + od_conv_win_num_cfgs() + 1; }
 
 extern "C" int od_conv_weight_dims(int cout, int cin, int ksize, int* cout_pad, int* kpad) {
   OD_REQUIRE(cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), "od_conv_weight_dims: bad dims");
@@ -459,9 +459,10 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
 
   int cfg = d->tile_cfg;
   if (cfg < 0) cfg = pick_cfg(ctx, M, d->Cin, d->Cout, d->ksize);
-  OD_REQUIRE(cfg < kNumCfgs + od_conv_win_num_cfgs(), "od_conv2d_fwd: tile_cfg %d out of range", cfg);
-  const bool use_win = cfg >= kNumCfgs;
-  const TileCfg& tc = g_cfgs[use_win ? 0 : cfg];
+  OD_REQUIRE(cfg < kNumCfgs + od_conv_win_num_cfgs() + 1, "od_conv2d_fwd: tile_cfg %d out of range", cfg);
+  const bool use_pw = cfg == kNumCfgs + od_conv_win_num_cfgs();
+  const bool use_win = cfg >= kNumCfgs && !use_pw;
+  const TileCfg& tc = g_cfgs[(use_win || use_pw) ? 0 : cfg];
 
   ConvKP p;
   p.x = (const f16*)d->x;
@@ -499,6 +500,33 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
       dbg = e ? atoi(e) : 0;
     }
     p.dbg = dbg;
+  }
+  if (use_pw) {
+    // persistent wave-specialised window kernel (conv_pw.hip)
+    p.splitk = 1;
+    p.steps_per_split = 0;
+    p.ws = nullptr;
+    ConvKernelInfo ki;
+    size_t lds = 0;
+    int np = 0, grid = 0, ntt = 0;
+    OD_REQUIRE(d->ksize == 3, "od_conv2d_fwd: tile_cfg %d is a 3x3 window kernel", cfg);
+    if (!od_conv_pw_select(p, ctx->num_cu, &ki, &lds, &np, &grid, &ntt)) {
+      od_set_error("od_conv2d_fwd: persistent window kernel does not support this shape (stride 1, Cin %% 64 == 0, W = %d)",
+                   d->W);
+      return OD_ERR_INVALID;
+    }
+    p.mtiles = od_ceil_div(M, ki.BM);
+    p.ntiles = od_ceil_div(d->Cout, ki.BN);
+    if (kernel_name) *kernel_name = ki.name;
+    if (dry_run) return OD_OK;
+    static size_t pw_attr = 0;
+    if (lds > pw_attr) {
+      OD_CHECK_HIP(hipFuncSetAttribute(ki.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      pw_attr = lds;
+    }
+    void* wargs[] = {&p, &np, &ntt};
+    OD_CHECK_HIP(hipLaunchKernel(ki.fn, dim3(grid), dim3(ki.threads), wargs, lds, stream));
+    return OD_OK;
   }
   if (use_win) {
     // LDS-window direct 3x3 (conv_win.hip); never split-K

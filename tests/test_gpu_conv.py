@@ -28,7 +28,8 @@ def _ref(x, w, scale, bias, stride, act, alpha, res=None, up2=False):
     return y
 
 
-NIG, NWIN = 21, 12   # implicit-GEMM tile configs 0..20, LDS-window configs 21..32 (od_conv_num_tile_cfgs == NIG + NWIN)
+NIG, NWIN = 21, 12   # implicit-GEMM tile configs 0..20, LDS-window configs 21..32, persistent window kernel 33
+NPW = NIG + NWIN
 SPEC0 = 13            # first wave-specialised implicit-GEMM config
 
 CASES = [
@@ -49,13 +50,20 @@ CASES += [(3, 10, 10, 128, 64, 1, 1, "elu", "none", c) for c in range(4, NIG)]  
 CASES += [(2, 10, 10, 512, 256, 3, 1, "leaky", "same", c) for c in range(SPEC0, NIG)]          # specialised, long K
 CASES += [(3, 10, 10, 256, 320, 3, 1, "elu", "none", c) for c in range(NIG, NIG + NWIN)]      # window: slice changes, ragged M/N
 CASES += [(1, 40, 40, 128, 256, 3, 1, "leaky", "same", c) for c in (NIG, NIG + 6, NIG + 8, NIG + 10)]  # W = 40
+CASES += [(2, 12, 12, 64, 128, 3, 1, "leaky", "same", NPW),          # persistent window kernel
+          (3, 10, 10, 256, 320, 3, 1, "elu", "none", NPW),           # 4 slices, ragged M and N
+          (1, 40, 40, 128, 256, 3, 1, "leaky", "same", NPW),
+          (2, 20, 20, 512, 128, 3, 1, "leaky", "up2", NPW),
+          (1, 3, 5, 64, 64, 3, 1, None, "none", NPW),
+          (9, 80, 80, 64, 256, 3, 1, "leaky", "same", NPW),          # 450 tiles > 256 CUs: workgroups walk 2 tiles
+          (5, 40, 40, 128, 1024, 3, 1, "leaky", "none", NPW)]        # 8 n-tiles, 2 slices
 CASES += [(2, 20, 20, 512, 128, 3, 1, "leaky", "up2", NIG + 3),                                 # 8 slices
           (1, 3, 5, 64, 64, 3, 1, None, "none", NIG + 1)]                                       # map smaller than a tile
 
 
 def test_config_table_size(cuda):
     from object_detector_amd import _lib
-    assert _lib.load().od_conv_num_tile_cfgs() == NIG + NWIN
+    assert _lib.load().od_conv_num_tile_cfgs() == NIG + NWIN + 1
 
 
 @pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
