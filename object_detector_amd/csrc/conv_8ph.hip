@@ -1,0 +1,423 @@
+// K1/K2 (large layers): implicit-GEMM convolution on a 256-wide, 8-wave, ONE-workgroup-per-CU schedule.
+//
+// The 128x128 kernels of conv_mfma.hip move 15.6 KB from L2 into LDS per MFLOP and pay one barrier per 32 MFMAs per
+// wave; they top out at ~35 % of the dense f16 MFMA peak.  This kernel halves the bytes per flop
+// (BM x 256 output tile, BM = 160..256) and runs the two waves of every SIMD half a phase apart, so that one of them is
+// always inside a 16-MFMA cluster while its partner issues LDS reads and the LDS-DMA of a later K tile:
+//
+//   waves 0-3 (wave row 0) and waves 4-7 (wave row 1) own (BM/2) x 64 output sub-tiles; waves 4-7 run one s_barrier
+//   behind waves 0-3 for the whole main loop.
+//   Per 64-deep K tile the wave does 4 phases = the 4 quadrants of its sub-tile, register operands reused:
+//     p0: read A-lo (4 m-frags) + B-lo (2 n-frags)   MFMA A-lo x B-lo     stage B-hi of tile t+1
+//     p1: read B-hi                                  MFMA A-lo x B-hi     stage A-hi of tile t+1
+//     p2: read A-hi (MF1 m-frags)                    MFMA A-hi x B-hi     stage A-lo of tile t+2
+//     p3: (B-lo still in registers)                  MFMA A-hi x B-lo     stage B-lo of tile t+2
+//   phase = { ds_read_b128 ..., 2 x global_load_lds_dwordx4, counted s_waitcnt vmcnt, s_barrier, 16 MFMA, s_barrier }.
+//   LDS = 2 K-tile buffers x 4 regions (A-lo, A-hi, B-lo, B-hi; 128 rows x 128 B each, chunk ^ (row & 7) swizzle on
+//   the DMA source side) = 128 KiB.  A region is re-staged no earlier than two phases after its last read, and read no
+//   earlier than one phase after the counted wait (+ barrier) that retires its DMA -- for both wave groups.
+//   vmcnt never drains to 0 in the steady state: every wait leaves the 4 youngest stages (8 DMAs per wave) in flight.
+//
+// A operand = activations gathered im2col-free (per-lane source = shifted input pixel or the zero page), B operand =
+// packed weights; tap walk, padding masks, XCD-aware tile order, split-K slabs and the epilogue are those of
+// conv_mfma.hip.  3x3 and 1x1, stride 1 and 2, Cin % 64 == 0.
+//
+// Replaces the Conv2D + BatchNormalization + LeakyReLU/ELU (+ Add) layers executed inside
+// `ObjectDetector.predict` (reference voc_validate.py:27; docs/MODEL.md:5-21).
+#include "conv_common.h"
+
+namespace {
+
+constexpr int E_BN = 256, E_BK = 64;
+constexpr int E_REGION = 128 * 128;       // one staged region: 128 rows x 64 f16
+constexpr int E_BUF = 4 * E_REGION;       // A-lo, A-hi, B-lo, B-hi
+constexpr int E_ALO = 0, E_AHI = E_REGION, E_BLO = 2 * E_REGION, E_BHI = 3 * E_REGION;
+
+// DBG & 32: s_memtime stamps of K tile 10, waves 0 and 4 of workgroup 0 (5 per phase: load part start, loads issued,
+// DMA wait done, MFMA start, MFMA done); read back with od_debug_e8_stamps
+__device__ unsigned long long g_e8_stamps[2][20];
+
+struct TapWalk {  // wave-uniform position of a K tile inside the (tap, cin) axis
+  int c0, tap, tapoff, dx;
+  int sel_tap;  // tap the cached per-lane offsets (a_sel) were selected for
+};
+
+constexpr unsigned E_OOB = 0x80000000u;  // buffer offset beyond any tensor this kernel accepts: the lane reads zeros
+
+// DBG (timing ablations only, results are garbage; selected by OD_CONV_DEBUG on the 3x3 / BM = 256 variant):
+//   1 = no LDS-DMA, 2 = no fragment reads and no MFMA, 8 = no MFMA, 16 = no fragment reads
+// BUF = 1: loaders are buffer_load_dwordx4 ... lds (resource in SGPRs, per-lane byte offset cached per filter tap,
+// K position in the scalar offset: no per-DMA address arithmetic, padding = out-of-range offset -> zeros);
+// BUF = 0: global_load_lds_dwordx4 with 64-bit per-lane addresses and the zero page (kept for A/B timing).
+template <int KS, int MF1, int DBG = 0, int BUF = 1>
+__global__ __launch_bounds__(512, 2) void od_conv_8ph(ConvKP p) {
+  constexpr int MF0 = 4, MT = MF0 + MF1, WROWS = MT * 16, BM = 2 * WROWS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  int logical;
+  {
+    const int nt = p.mtiles * p.ntiles;
+    const int pid = p.splitk > 1 ? (int)blockIdx.x / p.splitk : (int)blockIdx.x;
+    const int q = nt >> 3, r = nt & 7, xcd = pid & 7, loc = pid >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tm = logical / p.ntiles, tn = logical - tm * p.ntiles;
+  const int m0 = tm * BM, n0 = tn * E_BN;
+  const int nk_all = p.Ktot / E_BK;
+  const int ks0 = p.splitk > 1 ? ((int)blockIdx.x % p.splitk) * p.steps_per_split : 0;
+  const int nk = p.splitk > 1 ? min(p.steps_per_split, nk_all - ks0) : nk_all;
+  if (nk <= 0) return;
+
+  // ---- per-lane staging state: 64 rows x 8 chunks per DMA instruction of the workgroup --------------------------
+  const int rr = tid >> 3;
+  const int lc = (tid & 7) ^ (rr & 7);
+  int a_base[2][2];      // BUF: byte offset of the window-centre pixel (>= 0); else element offset of tap (0,0)
+  unsigned a_vmask[2][2];
+  unsigned a_sel[2][2];  // BUF: a_base or E_OOB for the tap the walk is at
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + j * WROWS + s * 64 + rr;
+      a_vmask[s][j] = 0u;
+      a_base[s][j] = 0;
+      if (m < p.M && (s == 0 || rr < MF1 * 16)) {
+        const unsigned b = (unsigned)m / (unsigned)p.HoWo;
+        const unsigned pix = (unsigned)m - b * (unsigned)p.HoWo;
+        const unsigned ho = pix / (unsigned)p.Wo;
+        const unsigned wo = pix - ho * (unsigned)p.Wo;
+        const int hi0 = (int)ho * p.stride - p.pad, wi0 = (int)wo * p.stride - p.pad;
+        a_base[s][j] = BUF ? ((((int)b * p.H + hi0 + p.pad) * p.W + wi0 + p.pad) * p.Cin + lc * 8) * 2
+                           : (((int)b * p.H + hi0) * p.W + wi0) * p.Cin + lc * 8;
+#pragma unroll
+        for (int t = 0; t < KS * KS; ++t) {
+          const int hi = hi0 + t / KS, wi = wi0 + t % KS;
+          if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) a_vmask[s][j] |= 1u << t;
+        }
+      }
+    }
+  int w_off[2][2];  // element offsets of this lane's weight rows
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + (2 * j + (rr >> 5)) * 64 + s * 32 + (rr & 31);
+      w_off[s][j] = (n * p.Kstride + lc * 8 + ks0 * E_BK) * (BUF ? 2 : 1);
+    }
+  // buffer resources: x is addressed from (pad rows + pad pixels) before its start so that the tap offset is >= 0
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.x - (long long)p.pad * (p.W + 1) * p.Cin), 0, (int)(p.x_bytes + (unsigned)(p.pad * (p.W + 1) * p.Cin * 2)),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+  auto blds16 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff, int soff, char* lptr) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lptr, 16, (int)voff, soff, 0, 0);
+  };
+
+  auto walk_init = [&](TapWalk& w, int kt) {
+    const int k0 = kt * E_BK;
+    if (KS == 3) {
+      w.sel_tap = -1;
+      w.tap = k0 / p.Cin;
+      w.c0 = k0 - w.tap * p.Cin;
+      const int dy = w.tap / 3;
+      w.dx = w.tap - dy * 3;
+      w.tapoff = (dy * p.W + w.dx) * p.Cin;
+    } else {
+      w.sel_tap = -1;
+      w.tap = 0;
+      w.c0 = k0;
+      w.dx = 0;
+      w.tapoff = 0;
+    }
+  };
+  auto walk_next = [&](TapWalk& w) {
+    w.c0 += E_BK;
+    if (KS == 3 && w.c0 >= p.Cin) {
+      w.c0 = 0;
+      ++w.tap;
+      if (++w.dx == 3) {
+        w.dx = 0;
+        w.tapoff += (p.W - 2) * p.Cin;
+      } else {
+        w.tapoff += p.Cin;
+      }
+    }
+  };
+  TapWalk walk_lo, walk_hi;  // next A-lo / A-hi tile to stage
+  walk_init(walk_lo, ks0);
+  walk_init(walk_hi, ks0);
+
+  char* const piece = smem + wave * 1024;  // this wave's 8 rows inside a 64-row DMA round
+  auto stage_a = [&](int s, TapWalk& w, int buf) {
+    if (DBG & 1) return;
+    if ((DBG & 64) && w.tap != 0) {  // ablation: A traffic of an LDS-window kernel (one DMA round per 9 K tiles)
+      walk_next(w);
+      return;
+    }
+    const int koff = w.tapoff + w.c0;
+    char* dst = piece + buf * E_BUF + (s ? E_AHI : E_ALO);
+    if (BUF) {
+      if (w.sel_tap != w.tap) {  // wave-uniform: once per filter tap
+        w.sel_tap = w.tap;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) a_sel[s][j] = ((a_vmask[s][j] >> w.tap) & 1u) ? (unsigned)a_base[s][j] : E_OOB;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) blds16(rs_x, a_sel[s][j], koff * 2, dst + j * 8192);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bool ok = (a_vmask[s][j] >> w.tap) & 1u;
+        const f16* src = ok ? p.x + (a_base[s][j] + koff) : p.zero;
+        glds16(src, dst + j * 8192);
+      }
+    }
+    walk_next(w);
+  };
+  auto stage_b = [&](int s, int t, int buf) {
+    if (DBG & 1) return;
+    char* dst = piece + buf * E_BUF + (s ? E_BHI : E_BLO);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (BUF) blds16(rs_w, (unsigned)w_off[s][j], t * (E_BK * 2), dst + j * 8192);
+      else glds16(p.w + (w_off[s][j] + t * E_BK), dst + j * 8192);
+    }
+  };
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: tile 0 complete + A-lo / B-lo of tile 1 -------------------------------------------------------
+  stage_a(0, walk_lo, 0);
+  stage_b(0, 0, 0);
+  stage_b(1, 0, 0);
+  stage_a(1, walk_hi, 0);
+  if (nk > 1) {
+    stage_a(0, walk_lo, 1);
+    stage_b(0, 1, 1);
+    wait_vmcnt<8>();
+  } else {
+    wait_vmcnt<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // wave row 1 runs one barrier behind wave row 0
+
+  // fragment read offsets: row (l15) x 128 B, chunk (kh*4 + lq) ^ (l15 & 7)
+  const int fa = (wr * 64 + l15) * 128 + ((lq ^ (l15 & 7)) * 16);
+  const int fb = (wc * 32 + l15) * 128 + ((lq ^ (l15 & 7)) * 16);
+
+  f16x8 xa[MF0][2], wlo[2][2], whi[2][2];
+  constexpr bool kRead = !(DBG & (2 | 16)), kMma = !(DBG & (2 | 8));
+  if (!kRead) {
+#pragma unroll
+    for (int f = 0; f < MF0; ++f)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) xa[f][kh] = f16x8{1, 1, 1, 1, 1, 1, 1, 1};
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) wlo[f][kh] = whi[f][kh] = f16x8{1, 1, 1, 1, 1, 1, 1, 1};
+  }
+  auto ldf = [&](f16x8& dst, const char* src) {
+    if (kRead) dst = *(const f16x8*)src;
+  };
+  auto mma = [&](f32x4& c, const f16x8& a, const f16x8& b) {
+    if (kMma) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    } else {
+      asm volatile("" ::"v"(a), "v"(b));
+    }
+  };
+  unsigned long long st[20];
+#define E8_STAMP(k)                                                     \
+  do {                                                                  \
+    if (DBG & 32) asm volatile("s_memtime %0" : "=s"(st[k])::"memory"); \
+  } while (0)
+  for (int t = 0; t < nk; ++t) {
+    const int cb = t & 1, nb = cb ^ 1;
+    const char* cur = smem + cb * E_BUF;
+    const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+
+    // ---------------- p0: A-lo x B-lo
+    E8_STAMP(0);
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) ldf(wlo[f][kh], cur + E_BLO + ((fb + f * 2048) ^ (kh * 64)));
+#pragma unroll
+    for (int f = 0; f < MF0; ++f)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) ldf(xa[f][kh], cur + E_ALO + ((fa + f * 2048) ^ (kh * 64)));
+    if (n1) {
+      stage_b(1, t + 1, nb);
+      E8_STAMP(1);
+      wait_vmcnt<8>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    E8_STAMP(2);
+    __builtin_amdgcn_s_barrier();
+    if (DBG & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    E8_STAMP(3);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int i = 0; i < MF0; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          mma(acc[i][j], wlo[j][kh], xa[i][kh]);
+    __builtin_amdgcn_s_setprio(0);
+    E8_STAMP(4);
+    __builtin_amdgcn_s_barrier();
+
+    // ---------------- p1: A-lo x B-hi
+    E8_STAMP(5);
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) ldf(whi[f][kh], cur + E_BHI + ((fb + f * 2048) ^ (kh * 64)));
+    if (n1) {
+      stage_a(1, walk_hi, nb);
+      E8_STAMP(6);
+      wait_vmcnt<8>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    E8_STAMP(7);
+    __builtin_amdgcn_s_barrier();
+    if (DBG & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    E8_STAMP(8);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int i = 0; i < MF0; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          mma(acc[i][2 + j], whi[j][kh], xa[i][kh]);
+    __builtin_amdgcn_s_setprio(0);
+    E8_STAMP(9);
+    __builtin_amdgcn_s_barrier();
+
+    // ---------------- p2: A-hi x B-hi
+    E8_STAMP(10);
+#pragma unroll
+    for (int f = 0; f < MF1; ++f)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) ldf(xa[f][kh], cur + E_AHI + ((fa + f * 2048) ^ (kh * 64)));
+    if (n2) stage_a(0, walk_lo, cb);
+    E8_STAMP(12);
+    __builtin_amdgcn_s_barrier();
+    if (DBG & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    E8_STAMP(13);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int i = 0; i < MF1; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          mma(acc[MF0 + i][2 + j], whi[j][kh], xa[i][kh]);
+    __builtin_amdgcn_s_setprio(0);
+    E8_STAMP(14);
+    __builtin_amdgcn_s_barrier();
+
+    // ---------------- p3: A-hi x B-lo (both still in registers)
+    E8_STAMP(15);
+    if (n2) {
+      stage_b(0, t + 2, cb);
+      E8_STAMP(16);
+      wait_vmcnt<8>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    E8_STAMP(17);
+    __builtin_amdgcn_s_barrier();
+    if (DBG & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    E8_STAMP(18);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int i = 0; i < MF1; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          mma(acc[MF0 + i][j], wlo[j][kh], xa[i][kh]);
+    __builtin_amdgcn_s_setprio(0);
+    E8_STAMP(19);
+    __builtin_amdgcn_s_barrier();
+    if ((DBG & 32) && t == 10 && blockIdx.x == 0 && (wave & 3) == 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < 20; ++k) g_e8_stamps[wr][k] = (k == 11) ? 0ull : st[k];
+    }
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the two wave groups
+  __syncthreads();
+
+  conv_epilogue<E_BN, 2, 4, MT, 4, 512>(p, smem, acc, m0, n0, tid, wr, wc, l15, lq);
+}
+
+struct E8Entry {
+  int BM;
+  const void* k1;
+  const void* k3;
+  const char* name1;
+  const char* name3;
+};
+#define OD_E8(MF1)                                                                                        \
+  {                                                                                                       \
+    32 * (4 + MF1), (const void*)&od_conv_8ph<1, MF1>, (const void*)&od_conv_8ph<3, MF1>,                 \
+        "od_conv_8ph<1, " #MF1 ">", "od_conv_8ph<3, " #MF1 ">"                                            \
+  }
+const E8Entry g_e8[] = {OD_E8(4), OD_E8(3), OD_E8(2), OD_E8(1)};  // BM = 256, 224, 192, 160
+const void* const g_e8_dbg[][2] = {{(const void*)&od_conv_8ph<3, 4, 1>, "od_conv_8ph<3, 4, dbg1>"},
+                                   {(const void*)&od_conv_8ph<3, 4, 2>, "od_conv_8ph<3, 4, dbg2>"},
+                                   {(const void*)&od_conv_8ph<3, 4, 8>, "od_conv_8ph<3, 4, dbg8>"},
+                                   {(const void*)&od_conv_8ph<3, 4, 16>, "od_conv_8ph<3, 4, dbg16>"},
+                                   {(const void*)&od_conv_8ph<3, 4, 32>, "od_conv_8ph<3, 4, dbg32>"},
+                                   {(const void*)&od_conv_8ph<3, 4, 64>, "od_conv_8ph<3, 4, dbg64>"},
+                                   {(const void*)&od_conv_8ph<3, 4, 0, 0>, "od_conv_8ph<3, 4, glds>"}};
+constexpr int kNumE8 = sizeof(g_e8) / sizeof(g_e8[0]);
+
+}  // namespace
+
+int od_conv_8ph_num_cfgs() { return kNumE8; }
+
+bool od_conv_8ph_select(int idx, const ConvKP& p, int ksize, ConvKernelInfo* info, size_t* lds_bytes) {
+  if (idx < 0 || idx >= kNumE8) return false;
+  if ((p.Cin & 63) != 0 || p.tconv) return false;
+  if (p.x_bytes >= 0x7F000000u || p.w_bytes >= 0x7F000000u || p.x_bytes == 0) return false;  // E_OOB must stay out of range
+  const E8Entry& e = g_e8[idx];
+  info->fn = ksize == 1 ? e.k1 : e.k3;
+  info->name = ksize == 1 ? e.name1 : e.name3;
+  if (idx == 0 && ksize == 3 && p.dbg) {
+    const int di = p.dbg == 1 ? 0 : p.dbg == 2 ? 1 : p.dbg == 8 ? 2 : p.dbg == 16 ? 3 : p.dbg == 32 ? 4 : p.dbg == 64 ? 5 : p.dbg == 128 ? 6 : -1;
+    if (di >= 0) {
+      info->fn = g_e8_dbg[di][0];
+      info->name = (const char*)g_e8_dbg[di][1];
+    }
+  }
+  info->BM = e.BM;
+  info->BN = E_BN;
+  info->threads = 512;
+  const size_t epi = (size_t)(e.BM / 2) * (E_BN + 4) * 4;
+  *lds_bytes = epi > (size_t)2 * E_BUF ? epi : (size_t)2 * E_BUF;
+  return true;
+}
+
+// debug only (not part of include/odhip.h): copies the s_memtime stamps of the OD_CONV_DEBUG=32 build to the host
+extern "C" int od_debug_e8_stamps(unsigned long long* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_e8_stamps), sizeof(unsigned long long) * 40) == hipSuccess ? 0 : -1;
+}

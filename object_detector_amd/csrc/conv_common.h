@@ -21,6 +21,7 @@ struct ConvKP {
   int splitk, steps_per_split;  // split-K (small-M layers): each workgroup reduces a K range, f32 atomics into ws
   float* ws;                    // [splitk][M][Cout] f32 partial slabs; od_conv_finish sums them and applies the epilogue
   int tconv, Hs, Ws;  // transposed (backward-data of a stride-2 conv): x is [B,Hs,Ws,Cin], gathered through a 2x zero-upsampled view
+  unsigned x_bytes, w_bytes;  // extents of x / packed w (buffer-addressed loaders: out-of-range lanes read zeros)
   int dbg;  // tuning ablations (OD_CONV_DEBUG): bit0 = skip the DMA, bit1 = skip fragment reads + MFMA
 };
 
@@ -166,4 +167,7 @@ int od_conv_win_num_cfgs();
 // conv_pw.hip: persistent wave-specialised window kernel (one variant)
 bool od_conv_pw_select(const ConvKP& p, int num_cu, ConvKernelInfo* info, size_t* lds_bytes, int* np_out, int* grid,
                        int* ntiles_total);
+// conv_8ph.hip: 8-wave, BM x 256 tile, one workgroup per CU, staggered wave groups (3x3 and 1x1)
+int od_conv_8ph_num_cfgs();
+bool od_conv_8ph_select(int idx, const ConvKP& p, int ksize, ConvKernelInfo* info, size_t* lds_bytes);
 bool od_conv_win_select(int idx, const ConvKP& p, ConvKernelInfo* info, size_t* lds_bytes);

@@ -399,6 +399,9 @@ const TileCfg g_cfgs[] = {
     OD_CFG_S2(128, 128, 64, 2, 2, 2, 4), // 18: register-staged loaders, 2 WG/CU
     OD_CFG_S2(64, 128, 64, 2, 2, 2, 4),  // 19
     OD_CFG_S2(256, 128, 64, 2, 2, 2, 2), // 20: 96 KiB, 1 WG/CU
+    OD_CFG(256, 256, 64, 2, 4, 4, 4),    // 21: 16 waves (4 per SIMD, wave tile 64x64), 128 KiB, 1 WG/CU
+    OD_CFG(256, 256, 32, 4, 4, 4, 4),    // 22: same, 32-deep steps, 4-deep ring
+    OD_CFG(256, 256, 32, 3, 4, 4, 4),    // 23: 3-deep ring (96 KiB)
 };
 constexpr int kNumCfgs = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
@@ -421,7 +424,7 @@ int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize) {
 
 }  // namespace
 
-extern "C" int od_conv_num_tile_cfgs(void) { return kNumCfgs + od_conv_win_num_cfgs() + 1; }
+extern "C" int od_conv_num_tile_cfgs(void) { return kNumCfgs + od_conv_win_num_cfgs() + 1 + od_conv_8ph_num_cfgs(); }
 
 extern "C" int od_conv_weight_dims(int cout, int cin, int ksize, int* cout_pad, int* kpad) {
   OD_REQUIRE(cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), "od_conv_weight_dims: bad dims");
@@ -459,10 +462,12 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
 
   int cfg = d->tile_cfg;
   if (cfg < 0) cfg = pick_cfg(ctx, M, d->Cin, d->Cout, d->ksize);
-  OD_REQUIRE(cfg < kNumCfgs + od_conv_win_num_cfgs() + 1, "od_conv2d_fwd: tile_cfg %d out of range", cfg);
-  const bool use_pw = cfg == kNumCfgs + od_conv_win_num_cfgs();
-  const bool use_win = cfg >= kNumCfgs && !use_pw;
-  const TileCfg& tc = g_cfgs[(use_win || use_pw) ? 0 : cfg];
+  const int cfg_pw = kNumCfgs + od_conv_win_num_cfgs(), cfg_e8 = cfg_pw + 1;
+  OD_REQUIRE(cfg < cfg_e8 + od_conv_8ph_num_cfgs(), "od_conv2d_fwd: tile_cfg %d out of range", cfg);
+  const bool use_pw = cfg == cfg_pw;
+  const bool use_e8 = cfg >= cfg_e8;
+  const bool use_win = cfg >= kNumCfgs && !use_pw && !use_e8;
+  TileCfg tc = g_cfgs[(use_win || use_pw || use_e8) ? 0 : cfg];
 
   ConvKP p;
   p.x = (const f16*)d->x;
@@ -491,6 +496,8 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
   p.alpha = d->alpha;
   p.res_mode = d->res_mode;
   p.out_f32 = d->out_dtype == OD_DT_F32;
+  p.x_bytes = (unsigned)((long long)d->B * d->H * d->W * d->Cin * 2);
+  p.w_bytes = (unsigned)((long long)od_round_up(d->Cout, 256) * p.Kstride * 2);
   p.obs = d->out_batch_stride ? d->out_batch_stride : (long long)p.HoWo * d->Cout;
   p.ops = d->out_pix_stride ? d->out_pix_stride : d->Cout;
   {
@@ -556,6 +563,20 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
     OD_CHECK_HIP(hipLaunchKernel(ki.fn, dim3(p.mtiles * p.ntiles), dim3(ki.threads), wargs, lds, stream));
     return OD_OK;
   }
+  ConvKernelInfo e8;
+  if (use_e8) {
+    // 8-wave / 256-wide schedule (conv_8ph.hip): same launch path (split-K slabs, finish kernel) as the table kernels
+    size_t lds = 0;
+    if (!od_conv_8ph_select(cfg - cfg_e8, p, d->ksize, &e8, &lds)) {
+      od_set_error("od_conv2d_fwd: tile_cfg %d (8-phase kernel) needs Cin %% 64 == 0 and no transposed gather", cfg);
+      return OD_ERR_INVALID;
+    }
+    tc.BM = e8.BM;
+    tc.BN = e8.BN;
+    tc.BK = 64;
+    tc.threads = e8.threads;
+    tc.lds = lds;
+  }
   p.mtiles = od_ceil_div(M, tc.BM);
   p.ntiles = od_ceil_div(d->Cout, tc.BN);
   // split-K for layers that cannot fill the chip with output tiles (batch-1 inference): every K-range workgroup writes
@@ -587,18 +608,19 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
 
   // kernel variant: 1x1 / 3x3-uniform-tap / 3x3-generic (odd channel counts fall back to a config that has one)
   int variant = d->ksize == 1 ? 0 : ((d->Cin % tc.BK) == 0 ? 1 : 2);
-  if (variant == 2 && !tc.k3g) {
+  if (!use_e8 && variant == 2 && !tc.k3g) {
     od_set_error("od_conv2d_fwd: tile_cfg %d needs Cin %% %d == 0 for 3x3 (Cin = %d); use cfg 0-3", cfg, tc.BK, d->Cin);
     return OD_ERR_INVALID;
   }
-  const void* fn = variant == 0 ? tc.k1 : (variant == 1 ? tc.k3 : tc.k3g);
-  if (kernel_name) *kernel_name = variant == 0 ? tc.name1 : (variant == 1 ? tc.name3 : tc.name3g);
+  const void* fn = use_e8 ? e8.fn : (variant == 0 ? tc.k1 : (variant == 1 ? tc.k3 : tc.k3g));
+  if (kernel_name) *kernel_name = use_e8 ? e8.name : (variant == 0 ? tc.name1 : (variant == 1 ? tc.name3 : tc.name3g));
   if (dry_run) return OD_OK;
 
-  static bool attr_done[kNumCfgs][3] = {};
-  if (!attr_done[cfg][variant]) {
+  static bool attr_done[kNumCfgs + 16][3] = {};
+  const int attr_slot = use_e8 ? kNumCfgs + (cfg - cfg_e8) : cfg;
+  if (!attr_done[attr_slot][variant]) {
     OD_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tc.lds));
-    attr_done[cfg][variant] = true;
+    attr_done[attr_slot][variant] = true;
   }
   void* args[] = {&p};
   OD_CHECK_HIP(hipLaunchKernel(fn, dim3(p.mtiles * p.ntiles * p.splitk), dim3(tc.threads), args, tc.lds, stream));

@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--cfgs", default="")
     ap.add_argument("--nores", action="store_true")
     ap.add_argument("--splitk", type=int, default=1)
+    ap.add_argument("--custom", default="", help="H,Cin,Cout,k,stride: one extra shape (used with --shapes custom)")
+    ap.add_argument("--reps", type=int, default=20)
     a = ap.parse_args()
     ctx = Context.get("cuda:0")
     ncfg = ctx.lib.od_conv_num_tile_cfgs()
@@ -74,13 +76,18 @@ def main():
              ("s3.a", S // 8, 256, 128, 1, 1), ("s4.a", S // 16, 512, 256, 1, 1), ("s5.a", S // 32, 1024, 512, 1, 1),
              ("h.t0.L1", S // 16, 256, 256, 3, 1), ("h.t0.L2", S // 32, 256, 256, 3, 1), ("h.out.L2", S // 32, 256, 208, 3, 1),
              ("s5.b", S // 32, 512, 1024, 3, 1), ("s4.b", S // 16, 256, 512, 3, 1)]
-    shapes = {"net": net, "big": big, "mid": mid, "w40": w40, "small": small, "all": net + big}[a.shapes]
+    custom = []
+    if a.custom:
+        h, ci, co, kk, st = (int(v) for v in a.custom.split(","))
+        custom = [("custom", h, ci, co, kk, st)]
+    shapes = {"custom": custom, "net": net, "big": big, "mid": mid, "w40": w40, "small": small, "all": net + big}[a.shapes]
     print(f"{'layer':8s} {'M':>8s} {'N':>5s} {'K':>5s} | " + " | ".join(f"cfg{c:<2d} us    TF/s" for c in cfgs))
     for name, H, Cin, Cout, k, st in shapes:
         row = []
         for c in cfgs:
             try:
-                us, tf = run(ctx, B, H, H, Cin, Cout, k, st, c, res=(k == 3 and st == 1 and not a.nores), splitk=a.splitk)
+                us, tf = run(ctx, B, H, H, Cin, Cout, k, st, c, res=(k == 3 and st == 1 and not a.nores), splitk=a.splitk,
+                             reps=a.reps)
                 row.append(f"{us:8.1f} {tf:7.1f}")
             except _lib.OdError:
                 row.append(f"{'-':>8s} {'-':>7s}")

@@ -28,7 +28,7 @@ def _ref(x, w, scale, bias, stride, act, alpha, res=None, up2=False):
     return y
 
 
-NIG, NWIN = 21, 12   # implicit-GEMM tile configs 0..20, LDS-window configs 21..32, persistent window kernel 33
+NIG, NWIN = 24, 12   # implicit-GEMM tile configs 0..23, LDS-window configs 24..35, persistent window kernel 36
 NPW = NIG + NWIN
 SPEC0 = 13            # first wave-specialised implicit-GEMM config
 
@@ -57,13 +57,25 @@ CASES += [(2, 12, 12, 64, 128, 3, 1, "leaky", "same", NPW),          # persisten
           (1, 3, 5, 64, 64, 3, 1, None, "none", NPW),
           (9, 80, 80, 64, 256, 3, 1, "leaky", "same", NPW),          # 450 tiles > 256 CUs: workgroups walk 2 tiles
           (5, 40, 40, 128, 1024, 3, 1, "leaky", "none", NPW)]        # 8 n-tiles, 2 slices
+NE8, NE8N = NPW + 1, 4   # 8-wave BM x 256 kernels (conv_8ph.hip): BM = 256, 224, 192, 160
+for _c in range(NE8, NE8 + NE8N):
+    CASES += [(2, 12, 12, 64, 128, 3, 1, "leaky", "same", _c),        # 9 K tiles, two m-tiles
+              (3, 10, 10, 256, 320, 3, 1, "elu", "none", _c),         # two n-tiles, ragged M and N
+              (1, 40, 40, 128, 256, 3, 1, "leaky", "same", _c),
+              (2, 20, 20, 512, 128, 3, 1, "leaky", "up2", _c),
+              (1, 3, 5, 64, 64, 3, 1, None, "none", _c),              # map smaller than a tile
+              (1, 20, 20, 256, 512, 3, 2, "leaky", "none", _c),       # stride 2
+              (2, 20, 20, 256, 128, 1, 1, "leaky", "none", _c),       # 1x1, 4 K tiles
+              (1, 10, 10, 64, 512, 1, 1, "elu", "same", _c),          # 1x1, ONE K tile
+              (1, 8, 8, 128, 64, 1, 1, None, "none", _c),             # 1x1, two K tiles
+              (3, 9, 7, 192, 208, 3, 1, "leaky", "same", _c)]         # Cin = 3 x 64, odd map
 CASES += [(2, 20, 20, 512, 128, 3, 1, "leaky", "up2", NIG + 3),                                 # 8 slices
           (1, 3, 5, 64, 64, 3, 1, None, "none", NIG + 1)]                                       # map smaller than a tile
 
 
 def test_config_table_size(cuda):
     from object_detector_amd import _lib
-    assert _lib.load().od_conv_num_tile_cfgs() == NIG + NWIN + 1
+    assert _lib.load().od_conv_num_tile_cfgs() == NIG + NWIN + 1 + NE8N
 
 
 @pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
@@ -104,6 +116,9 @@ def test_conv_matches_oracle(cuda, case):
     (1, 20, 20, 256, 512, 3, 2, "leaky", "none", 2, 0),     # stride 2
     (1, 10, 10, 256, 208, 3, 1, None, "none", 3, 5),        # ragged Cout, generic-capable config
     (2, 6, 6, 40, 72, 3, 1, "leaky", "same", 3, 3),         # non-uniform taps (Cin = 40) + split
+    (1, 10, 10, 512, 1024, 3, 1, "leaky", "same", 37, 6),   # 8-wave kernel, 12 K tiles per split
+    (2, 10, 10, 512, 304, 3, 1, "elu", "none", 39, 5),      # BM = 192, uneven split (72 tiles / 5)
+    (1, 20, 20, 512, 256, 1, 1, "elu", "up2", 38, 4),       # 1x1, 2 K tiles per split
 ], ids=str)
 def test_conv_split_k(cuda, case):
     """split-K path: per-split f32 slabs + finish kernel summing them in a fixed order (bit-reproducible)."""
