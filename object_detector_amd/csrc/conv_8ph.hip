@@ -44,6 +44,88 @@ struct TapWalk {  // wave-uniform position of a K tile inside the (tap, cin) axi
 
 constexpr unsigned E_OOB = 0x80000000u;  // buffer offset beyond any tensor this kernel accepts: the lane reads zeros
 
+// Epilogue straight from the accumulators (no LDS staging, no barrier).  After v_mfma_f32_16x16x32 with the weights as
+// the A operand a lane (pixel l15, quad lq) holds channels lq*4..lq*4+3 of every 16-channel fragment.  One
+// v_permlane16_swap per element on a PAIR of fragments (j, j+1) leaves every lane with 8 CONSECUTIVE channels of its
+// pixel -- even lane rows get fragment j, odd rows fragment j+1 -- so scale/bias/activation/residual run in f32 on a
+// 16-byte residual load and end in one 16-byte NHWC store (one rounding to f16), 64 contiguous bytes per pixel per
+// instruction.  Same arithmetic and rounding points as conv_epilogue.
+template <int MT>
+static __device__ __forceinline__ void e8_epilogue_direct(const ConvKP& p, f32x4 (&acc)[MT][4], int m0w, int n0w, int l15,
+                                                          int lq) {
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    const int n = n0w + (2 * pr + (lq & 1)) * 16 + (lq >> 1) * 8;  // this lane's 8 channels
+    const bool nok = n < p.Cout;
+    float sc[8], bi[8];
+    {
+      const f32x4 s0 = *(const f32x4*)(p.scale + n), s1 = *(const f32x4*)(p.scale + n + 4);
+      const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc[e] = s0[e];
+        sc[4 + e] = s1[e];
+        bi[e] = b0[e];
+        bi[4 + e] = b1[e];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0w + i * 16 + l15;
+      const bool ok = nok && m < p.M;
+      const unsigned b = (unsigned)m / (unsigned)p.HoWo;
+      const unsigned pix = (unsigned)m - b * (unsigned)p.HoWo;
+      f16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ok && p.res_mode != OD_RES_NONE) {
+        long long roff;
+        if (p.res_mode == OD_RES_SAME) {
+          roff = (long long)m * p.Cout + n;
+        } else {
+          const unsigned ho = pix / (unsigned)p.Wo, wo = pix - ho * (unsigned)p.Wo;
+          roff = ((long long)(b * (unsigned)(p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout + n;
+        }
+        r = *(const f16x8*)(p.res + roff);
+      }
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // inline asm: hipcc (ROCm 7.2) folds several __builtin_amdgcn_permlane16_swap calls of one unrolled loop into
+        // one.  The instruction rewrites BOTH operands; s_nop covers the VALU-write -> permlane-read wait states.
+        float a = acc[i][2 * pr][e], bq = acc[i][2 * pr + 1][e];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(bq));
+        v[e] = a;
+        v[4 + e] = bq;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
+      if (p.act == OD_ACT_LEAKY) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+      } else if (p.act == OD_ACT_ELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : p.alpha * od_expm1_fast(v[e]);
+      }
+      if (p.res_mode != OD_RES_NONE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+      }
+      if (ok) {
+        const long long ooff = (long long)b * p.obs + (long long)pix * p.ops + n;
+        if (p.out_f32) {
+          float* o = (float*)p.out + ooff;
+          *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
+          *(f32x4*)(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          f16x8 h;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) h[e] = (f16)v[e];
+          *(f16x8*)((f16*)p.out + ooff) = h;
+        }
+      }
+    }
+  }
+}
+
 // DBG (timing ablations only, results are garbage; selected by OD_CONV_DEBUG on the 3x3 / BM = 256 variant):
 //   1 = no LDS-DMA, 2 = no fragment reads and no MFMA, 8 = no MFMA, 16 = no fragment reads
 // BUF = 1: loaders are buffer_load_dwordx4 ... lds (resource in SGPRs, per-lane byte offset cached per filter tap,
@@ -54,6 +136,12 @@ __global__ __launch_bounds__(512, 2) void od_conv_8ph(ConvKP p) {
   constexpr int MF0 = 4, MT = MF0 + MF1, WROWS = MT * 16, BM = 2 * WROWS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  unsigned long long cst[4] = {0, 0, 0, 0};
+#define E8_CSTAMP(k)                                                                               \
+  do {                                                                                             \
+    if (DBG & 32) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cst[k])::"memory"); \
+  } while (0)
+  E8_CSTAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -209,7 +297,6 @@ __global__ __launch_bounds__(512, 2) void od_conv_8ph(ConvKP p) {
     wait_vmcnt<0>();
   }
   __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // wave row 1 runs one barrier behind wave row 0
 
   // fragment read offsets: row (l15) x 128 B, chunk (kh*4 + lq) ^ (l15 & 7)
   const int fa = (wr * 64 + l15) * 128 + ((lq ^ (l15 & 7)) * 16);
@@ -237,17 +324,15 @@ __global__ __launch_bounds__(512, 2) void od_conv_8ph(ConvKP p) {
       asm volatile("" ::"v"(a), "v"(b));
     }
   };
-  unsigned long long st[20];
+  unsigned long long st[16];
 #define E8_STAMP(k)                                                     \
   do {                                                                  \
-    if (DBG & 32) asm volatile("s_memtime %0" : "=s"(st[k])::"memory"); \
+    if (DBG & 32) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[k])::"memory"); \
   } while (0)
-  for (int t = 0; t < nk; ++t) {
-    const int cb = t & 1, nb = cb ^ 1;
-    const char* cur = smem + cb * E_BUF;
-    const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
 
-    // ---------------- p0: A-lo x B-lo
+  // ---- the four load parts (fragment reads of this phase + LDS-DMA of a later tile + counted wait) and MFMA parts
+  auto L0 = [&](int t) {
+    const char* cur = smem + (t & 1) * E_BUF;
     E8_STAMP(0);
 #pragma unroll
     for (int f = 0; f < 2; ++f)
@@ -257,116 +342,134 @@ __global__ __launch_bounds__(512, 2) void od_conv_8ph(ConvKP p) {
     for (int f = 0; f < MF0; ++f)
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) ldf(xa[f][kh], cur + E_ALO + ((fa + f * 2048) ^ (kh * 64)));
-    if (n1) {
-      stage_b(1, t + 1, nb);
-      E8_STAMP(1);
-      wait_vmcnt<8>();
+    if (t + 1 < nk) {
+      stage_b(1, t + 1, (t & 1) ^ 1);
+      wait_vmcnt<8>();  // B-hi of tile t (read in the next phase) has landed
     } else {
       wait_vmcnt<0>();
     }
-    E8_STAMP(2);
-    __builtin_amdgcn_s_barrier();
-    if (DBG & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    E8_STAMP(3);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-      for (int i = 0; i < MF0; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          mma(acc[i][j], wlo[j][kh], xa[i][kh]);
-    __builtin_amdgcn_s_setprio(0);
+    E8_STAMP(1);
+  };
+  auto L1 = [&](int t) {
+    const char* cur = smem + (t & 1) * E_BUF;
     E8_STAMP(4);
-    __builtin_amdgcn_s_barrier();
-
-    // ---------------- p1: A-lo x B-hi
-    E8_STAMP(5);
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) ldf(whi[f][kh], cur + E_BHI + ((fb + f * 2048) ^ (kh * 64)));
-    if (n1) {
-      stage_a(1, walk_hi, nb);
-      E8_STAMP(6);
-      wait_vmcnt<8>();
+    if (t + 1 < nk) {
+      stage_a(1, walk_hi, (t & 1) ^ 1);
+      wait_vmcnt<8>();  // A-hi of tile t
     } else {
       wait_vmcnt<0>();
     }
-    E8_STAMP(7);
-    __builtin_amdgcn_s_barrier();
-    if (DBG & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    E8_STAMP(5);
+  };
+  auto L2 = [&](int t) {
+    const char* cur = smem + (t & 1) * E_BUF;
     E8_STAMP(8);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-      for (int i = 0; i < MF0; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          mma(acc[i][2 + j], whi[j][kh], xa[i][kh]);
-    __builtin_amdgcn_s_setprio(0);
-    E8_STAMP(9);
-    __builtin_amdgcn_s_barrier();
-
-    // ---------------- p2: A-hi x B-hi
-    E8_STAMP(10);
 #pragma unroll
     for (int f = 0; f < MF1; ++f)
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) ldf(xa[f][kh], cur + E_AHI + ((fa + f * 2048) ^ (kh * 64)));
-    if (n2) stage_a(0, walk_lo, cb);
+    if (t + 2 < nk) stage_a(0, walk_lo, t & 1);
+    E8_STAMP(9);
+  };
+  auto L3 = [&](int t) {
     E8_STAMP(12);
-    __builtin_amdgcn_s_barrier();
-    if (DBG & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    E8_STAMP(13);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-      for (int i = 0; i < MF1; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          mma(acc[MF0 + i][2 + j], whi[j][kh], xa[i][kh]);
-    __builtin_amdgcn_s_setprio(0);
-    E8_STAMP(14);
-    __builtin_amdgcn_s_barrier();
-
-    // ---------------- p3: A-hi x B-lo (both still in registers)
-    E8_STAMP(15);
-    if (n2) {
-      stage_b(0, t + 2, cb);
-      E8_STAMP(16);
-      wait_vmcnt<8>();
+    if (t + 2 < nk) {
+      stage_b(0, t + 2, t & 1);
+      wait_vmcnt<8>();  // A-lo and B-lo of tile t+1
     } else {
       wait_vmcnt<0>();
     }
-    E8_STAMP(17);
-    __builtin_amdgcn_s_barrier();
+    E8_STAMP(13);
+  };
+  auto M = [&](int ph) {  // ph is a literal at every call site
     if (DBG & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    E8_STAMP(18);
+    E8_STAMP(ph * 4 + 2);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-      for (int i = 0; i < MF1; ++i)
+      for (int i = 0; i < ((ph < 2) ? MF0 : MF1); ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          mma(acc[MF0 + i][j], wlo[j][kh], xa[i][kh]);
+        for (int j = 0; j < 2; ++j) {
+          if (ph == 0) mma(acc[i][j], wlo[j][kh], xa[i][kh]);
+          if (ph == 1) mma(acc[i][2 + j], whi[j][kh], xa[i][kh]);
+          if (ph == 2) mma(acc[MF0 + i][2 + j], whi[j][kh], xa[i][kh]);
+          if (ph == 3) mma(acc[MF0 + i][j], wlo[j][kh], xa[i][kh]);
+        }
     __builtin_amdgcn_s_setprio(0);
-    E8_STAMP(19);
-    __builtin_amdgcn_s_barrier();
+    E8_STAMP(ph * 4 + 3);
+  };
+  auto dump_stamps = [&](int t) {
     if ((DBG & 32) && t == 10 && blockIdx.x == 0 && (wave & 3) == 0) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0)
 #pragma unroll
-        for (int k = 0; k < 20; ++k) g_e8_stamps[wr][k] = (k == 11) ? 0ull : st[k];
+        for (int k = 0; k < 16; ++k) g_e8_stamps[wr][k] = st[k];
+    }
+  };
+
+  E8_CSTAMP(1);
+  // ONE barrier per phase.  Wave row 0 runs { load part, MFMA part } between two barriers, wave row 1 runs { MFMA part
+  // of the previous phase, load part }: on every SIMD one wave is in its MFMA cluster while its partner issues reads
+  // and DMAs, and neither waits for the other in between.  Both rows read, stage and wait for phase P in the same
+  // barrier interval, so the LDS hazards are those of an unskewed loop: read one interval after the counted wait,
+  // re-stage a region two or more intervals after its last read.
+  if (wr == 0) {
+    for (int t = 0; t < nk; ++t) {
+      L0(t);
+      M(0);
+      __builtin_amdgcn_s_barrier();
+      L1(t);
+      M(1);
+      __builtin_amdgcn_s_barrier();
+      L2(t);
+      M(2);
+      __builtin_amdgcn_s_barrier();
+      L3(t);
+      M(3);
+      __builtin_amdgcn_s_barrier();
+      dump_stamps(t);
+    }
+  } else {
+    L0(0);
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nk; ++t) {
+      M(0);
+      L1(t);
+      __builtin_amdgcn_s_barrier();
+      M(1);
+      L2(t);
+      __builtin_amdgcn_s_barrier();
+      M(2);
+      L3(t);
+      __builtin_amdgcn_s_barrier();
+      M(3);
+      if (t + 1 < nk) {
+        L0(t + 1);
+        __builtin_amdgcn_s_barrier();
+      }
+      dump_stamps(t);
     }
   }
-  if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the two wave groups
   __syncthreads();
+  E8_CSTAMP(2);
 
-  conv_epilogue<E_BN, 2, 4, MT, 4, 512>(p, smem, acc, m0, n0, tid, wr, wc, l15, lq);
+  if (p.splitk > 1) {
+    conv_epilogue<E_BN, 2, 4, MT, 4, 512>(p, smem, acc, m0, n0, tid, wr, wc, l15, lq);  // f32 partial slabs
+  } else {
+    e8_epilogue_direct<MT>(p, acc, m0 + wr * WROWS, n0 + wc * 64, l15, lq);
+  }
+  if (DBG & 32) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    E8_CSTAMP(3);
+    if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g_e8_stamps[wr][16 + k] = cst[k];
+  }
 }
 
 struct E8Entry {

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void od_conv_finish(ConvKP p) {
     for (int e = 0; e < 8; ++e) {
       v[e] = v[e] * p.scale[n + e] + p.bias[n + e];
       if (p.act == OD_ACT_LEAKY) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
-      else if (p.act == OD_ACT_ELU) v[e] = v[e] > 0.f ? v[e] : p.alpha * expm1f(v[e]);
+      else if (p.act == OD_ACT_ELU) v[e] = v[e] > 0.f ? v[e] : p.alpha * od_expm1_fast(v[e]);
     }
     const unsigned b = (unsigned)m / (unsigned)p.HoWo;
     const unsigned pix = (unsigned)m - b * (unsigned)p.HoWo;
@@ -406,7 +406,7 @@ const TileCfg g_cfgs[] = {
 constexpr int kNumCfgs = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
 // Tile choice from the measured table (profiles/r01/conv_cfg_sweep.txt; MI355X, batch-32 Darknet53 shapes).
-int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize) {
+int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize, bool e8_ok) {
   const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
   const bool spec_ok = (Cin % 64) == 0;  // wave-specialised kernels are tap-uniform only
   if (Cout <= 64) return (ksize == 3 && od_ceil_div(M, 128) >= 8 * cus) ? 1 : 3;
@@ -414,10 +414,30 @@ int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize) {
   if (ksize == 1) {
     if (!spec_ok || M <= 4096) return 3;
     if (M <= 16384) return 17;
-    return Cout >= 256 ? 13 : 3;
+    if (Cout < 256) return 3;
+    // wide 1x1 (neck laterals): fall through to the 128x128 / 8-wave comparison below
+    if (t128 < cus) return 13;
   }
   if (!spec_ok) return t128 >= 2L * cus ? 0 : 2;
-  if (t128 >= cus) return (Cout == 128) ? 2 : 13;  // 4 MFMA waves + 4 DMA waves, 2 workgroups per CU
+  if (t128 >= cus) {
+    if (Cout == 128) return 2;
+    // 128x128 specialised kernel (2 workgroups per CU) vs the 8-wave BM x 256 kernel (1 per CU): whole rounds x
+    // (fixed cost + K tiles x cost per tile), constants in us from profiles/r01/conv_8ph_sweep_{320,640}.txt
+    const int nk = od_ceil_div(ksize * ksize * Cin, 64);
+    const double c13 = (double)od_ceil_div((int)t128, 2 * cus) * (7.5 + 1.07 * nk);
+    double best = 0.93 * c13;
+    int pick = 13;
+    for (int i = 0; e8_ok && i < od_conv_8ph_num_cfgs(); ++i) {
+      const int mt = 8 - i, bm = 32 * mt;
+      const long tiles = (long)od_ceil_div(M, bm) * od_ceil_div(Cout, 256);
+      const double c = (double)((tiles + cus - 1) / cus) * (13.0 + 1.78 * nk * (0.5 + 0.0625 * mt));
+      if (c < best) {
+        best = c;
+        pick = kNumCfgs + od_conv_win_num_cfgs() + 1 + i;
+      }
+    }
+    return pick;
+  }
   if (Cout <= 256) return M <= 4096 ? 3 : 17;      // few, narrow tiles (prediction module on the coarse levels)
   return 14;                                       // few tiles, long K: one deep-ring workgroup per CU
 }
@@ -461,7 +481,9 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
   const int M = (int)M64;
 
   int cfg = d->tile_cfg;
-  if (cfg < 0) cfg = pick_cfg(ctx, M, d->Cin, d->Cout, d->ksize);
+  if (cfg < 0)
+    cfg = pick_cfg(ctx, M, d->Cin, d->Cout, d->ksize,
+                   !tconv && (long long)d->B * d->H * d->W * d->Cin * 2 < 0x7F000000LL);
   const int cfg_pw = kNumCfgs + od_conv_win_num_cfgs(), cfg_e8 = cfg_pw + 1;
   OD_REQUIRE(cfg < cfg_e8 + od_conv_8ph_num_cfgs(), "od_conv2d_fwd: tile_cfg %d out of range", cfg);
   const bool use_pw = cfg == cfg_pw;

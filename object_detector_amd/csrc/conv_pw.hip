@@ -232,7 +232,7 @@ __global__ __launch_bounds__(768, 3) void od_conv3x3_pw(ConvKP p, int np, int nt
                 for (int e = 0; e < 4; ++e) {
                   float t = acc[i][j][e] * sc[e] + bi[e];
                   if (p.act == OD_ACT_LEAKY) t = t > 0.f ? t : t * p.alpha;
-                  else if (p.act == OD_ACT_ELU) t = t > 0.f ? t : p.alpha * expm1f(t);
+                  else if (p.act == OD_ACT_ELU) t = t > 0.f ? t : p.alpha * od_expm1_fast(t);
                   v[e] = t;
                 }
                 if (p.res_mode != OD_RES_NONE) {

@@ -76,11 +76,13 @@ def main():
              ("s3.a", S // 8, 256, 128, 1, 1), ("s4.a", S // 16, 512, 256, 1, 1), ("s5.a", S // 32, 1024, 512, 1, 1),
              ("h.t0.L1", S // 16, 256, 256, 3, 1), ("h.t0.L2", S // 32, 256, 256, 3, 1), ("h.out.L2", S // 32, 256, 208, 3, 1),
              ("s5.b", S // 32, 512, 1024, 3, 1), ("s4.b", S // 16, 256, 512, 3, 1)]
+    head = [("h.out.L0", S // 8, 256, 208, 3, 1), ("h.t0.L0", S // 8, 256, 256, 3, 1), ("h.t0.L1", S // 16, 256, 256, 3, 1),
+            ("h.out.L1", S // 16, 256, 208, 3, 1), ("n.lat3", S // 8, 256, 256, 1, 1)]
     custom = []
     if a.custom:
         h, ci, co, kk, st = (int(v) for v in a.custom.split(","))
         custom = [("custom", h, ci, co, kk, st)]
-    shapes = {"custom": custom, "net": net, "big": big, "mid": mid, "w40": w40, "small": small, "all": net + big}[a.shapes]
+    shapes = {"custom": custom, "net": net, "big": big, "mid": mid, "w40": w40, "small": small, "head": head, "nethead": net + head, "all": net + big}[a.shapes]
     print(f"{'layer':8s} {'M':>8s} {'N':>5s} {'K':>5s} | " + " | ".join(f"cfg{c:<2d} us    TF/s" for c in cfgs))
     for name, H, Cin, Cout, k, st in shapes:
         row = []

@@ -13,17 +13,16 @@ import bench_conv  # noqa: E402
 from object_detector_amd.net import Context  # noqa: E402
 
 ctx = Context.get("cuda:0")
-us, tf = bench_conv.run(ctx, 16, 64, 64, 256, 256, 3, 1, 34, reps=5, res=False)
+us, tf = bench_conv.run(ctx, 16, 64, 64, 256, 256, 3, 1, 37, reps=5, res=False)
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * 40)()
 assert ctx.lib.od_debug_e8_stamps(buf) == 0
 print(f"{us:.1f} us {tf:.1f} TF/s")
-names = ["load0", "issued", "dma_ok", "mfma0", "mfma1"]
+names = ["L0", "L1", "M0", "M1"]
+t0 = min(buf[0], buf[20])
 for g in range(2):
     st = list(buf[g * 20:(g + 1) * 20])
-    base = st[0]
-    print(f"wave group {g}:")
+    print('  coarse: prologue %d  mainloop %d  epilogue %d cycles' % (st[17] - st[16], st[18] - st[17], st[19] - st[18]))
+    print(f"wave row {g}:")
     for ph in range(4):
-        row = [st[ph * 5 + k] - base if st[ph * 5 + k] else -1 for k in range(5)]
-        print(f"  p{ph}: " + "  ".join(f"{n}={v:6d}" for n, v in zip(names, row)))
-print("group1.load0 - group0.load0 =", buf[20] - buf[0])
+        print(f"  p{ph}: " + "  ".join(f"{n}={st[ph * 4 + k] - t0:6d}" for k, n in enumerate(names)))
