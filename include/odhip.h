@@ -93,6 +93,28 @@ int od_conv_weight_dims(int cout, int cin, int ksize, int* cout_pad, int* kpad);
 int od_conv_num_tile_cfgs(void);
 int od_conv2d_fwd(od_ctx* ctx, const od_conv_desc* d, void* stream);
 
+/* K1+K2 fused residual block of the early Darknet53 stages (one launch instead of two layers + add):
+ *   out = x + act(scale3 * conv3x3(act(scale1 * conv1x1(x) + bias1)) + bias3)
+ * x, out f16 [B,H,W,C]; the middle tensor has C/2 channels and never leaves the CU.  w1 / w3 are the packed weights
+ * of the 1x1 (C -> C/2) and 3x3 (C/2 -> C) convolutions exactly as od_conv2d_fwd takes them.  Supported: C in {64, 128},
+ * H and W multiples of 16 (od_bottleneck_supported); everything else runs as two od_conv2d_fwd calls.
+ * Replaces the same Keras layers as od_conv2d_fwd (reference voc_validate.py:27; docs/MODEL.md:15-17). */
+typedef struct od_bneck_desc {
+  const void* x;
+  const void* w1;
+  const float* scale1;
+  const float* bias1;
+  const void* w3;
+  const float* scale3;
+  const float* bias3;
+  void* out;
+  int32_t B, H, W, C;
+  int32_t act; /* OD_ACT_*, both convolutions */
+  float alpha;
+} od_bneck_desc;
+int od_bottleneck_supported(int H, int W, int C);
+int od_bottleneck_fwd(od_ctx* ctx, const od_bneck_desc* d, void* stream);
+
 /* K3: first layer, uint8 RGB image in, 3x3 stride-1 conv 3->Cout (Cout = 32), input normalisation folded
  * into scale.  x u8 [B,H,W,3]; w f16 packed [Cout][32] (k = (dy*3+dx)*3 + c, k >= 27 zero);
  * out f16 [B,H,W,Cout].  Replaces the image preprocess + first Conv2D of predict (voc_validate.py:27). */
@@ -238,11 +260,13 @@ int od_augment_batch(od_ctx* ctx, const uint8_t* src, const void* params, uint8_
  * ---------------------------------------------------------------------------------------------- */
 #define OD_OP_CONV 1
 #define OD_OP_CONV_FIRST 2
+#define OD_OP_BNECK 3
 
 typedef struct od_plan_op {
   int32_t kind; /* OD_OP_* */
   int32_t pad_;
   od_conv_desc conv; /* OD_OP_CONV; OD_OP_CONV_FIRST uses x(u8), w, scale, bias, out, B,H,W,Cout,act,alpha */
+  od_bneck_desc bneck; /* OD_OP_BNECK */
 } od_plan_op;
 
 typedef struct od_plan od_plan;

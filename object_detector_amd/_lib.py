@@ -15,7 +15,7 @@ LIB_PATH = _HERE / "libodhip.so"
 OD_ACT_LINEAR, OD_ACT_LEAKY, OD_ACT_ELU = 0, 1, 2
 OD_RES_NONE, OD_RES_SAME, OD_RES_UP2 = 0, 1, 2
 OD_DT_F16, OD_DT_F32 = 0, 1
-OD_OP_CONV, OD_OP_CONV_FIRST = 1, 2
+OD_OP_CONV, OD_OP_CONV_FIRST, OD_OP_BNECK = 1, 2, 3
 
 ACT_ENUM = {None: OD_ACT_LINEAR, "linear": OD_ACT_LINEAR, "leaky": OD_ACT_LEAKY, "elu": OD_ACT_ELU}
 
@@ -40,8 +40,17 @@ class AugParams(C.Structure):
                 ("n_erase", C.c_int32), ("erase", (C.c_float * 4) * 3), ("erase_rgb", (C.c_uint8 * 4) * 3)]
 
 
+class BneckDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w1", C.c_void_p), ("scale1", C.c_void_p), ("bias1", C.c_void_p),
+        ("w3", C.c_void_p), ("scale3", C.c_void_p), ("bias3", C.c_void_p), ("out", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+        ("act", C.c_int32), ("alpha", C.c_float),
+    ]
+
+
 class PlanOp(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("pad_", C.c_int32), ("conv", ConvDesc)]
+    _fields_ = [("kind", C.c_int32), ("pad_", C.c_int32), ("conv", ConvDesc), ("bneck", BneckDesc)]
 
 
 class OdError(RuntimeError):
@@ -59,6 +68,8 @@ _PROTOS = {
     "od_conv_weight_dims": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "od_conv_num_tile_cfgs": (C.c_int, []),
     "od_conv2d_fwd": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_void_p]),
+    "od_bottleneck_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "od_bottleneck_fwd": (C.c_int, [C.c_void_p, C.POINTER(BneckDesc), C.c_void_p]),
     "od_conv_first_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "od_upsample2x_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -65,6 +65,7 @@ static int run_op(od_plan* pl, int i, hipStream_t s) {
     return od_conv_first_fwd(pl->ctx, (const uint8_t*)c.x, c.w, c.scale, c.bias, c.out, c.B, c.H, c.W, c.Cout, c.act,
                              c.alpha, s);
   }
+  if (op.kind == OD_OP_BNECK) return od_bottleneck_fwd(pl->ctx, &op.bneck, s);
   od_set_error("od_plan: unknown op kind %d at %d", op.kind, i);
   return OD_ERR_INVALID;
 }
@@ -86,6 +87,14 @@ extern "C" int od_plan_create(od_ctx* ctx, const od_plan_op* ops, int n_ops, od_
       pl->names[i] = nm;
     } else if (ops[i].kind == OD_OP_CONV_FIRST) {
       pl->names[i] = od_conv_first_kernel_name();
+    } else if (ops[i].kind == OD_OP_BNECK) {
+      if (!od_bottleneck_supported(ops[i].bneck.H, ops[i].bneck.W, ops[i].bneck.C)) {
+        od_set_error("od_plan_create: op %d: fused block unsupported for C=%d, %dx%d", i, ops[i].bneck.C, ops[i].bneck.H,
+                     ops[i].bneck.W);
+        delete pl;
+        return OD_ERR_INVALID;
+      }
+      pl->names[i] = od_bottleneck_kernel_name(ops[i].bneck.C);
     } else {
       od_set_error("od_plan_create: unknown op kind %d at %d", ops[i].kind, i);
       delete pl;

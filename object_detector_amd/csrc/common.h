@@ -53,3 +53,4 @@ static inline int od_round_up(int a, int b) { return od_ceil_div(a, b) * b; }
 int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, const char** kernel_name,
                        bool dry_run);
 const char* od_conv_first_kernel_name();
+const char* od_bottleneck_kernel_name(int C);

@@ -89,10 +89,8 @@ static __device__ __forceinline__ void e8_epilogue_direct(const ConvKP& p, f32x4
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        // inline asm: hipcc (ROCm 7.2) folds several __builtin_amdgcn_permlane16_swap calls of one unrolled loop into
-        // one.  The instruction rewrites BOTH operands; s_nop covers the VALU-write -> permlane-read wait states.
         float a = acc[i][2 * pr][e], bq = acc[i][2 * pr + 1][e];
-        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(bq));
+        od_permlane16_swap(a, bq);
         v[e] = a;
         v[4 + e] = bq;
       }
@@ -100,7 +98,7 @@ static __device__ __forceinline__ void e8_epilogue_direct(const ConvKP& p, f32x4
       for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
       if (p.act == OD_ACT_LEAKY) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+        for (int e = 0; e < 8; ++e) v[e] = od_leaky(v[e], p.alpha);
       } else if (p.act == OD_ACT_ELU) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : p.alpha * od_expm1_fast(v[e]);
@@ -461,6 +459,7 @@ __global__ __launch_bounds__(512, 2) void od_conv_8ph(ConvKP p) {
   if (p.splitk > 1) {
     conv_epilogue<E_BN, 2, 4, MT, 4, 512>(p, smem, acc, m0, n0, tid, wr, wc, l15, lq);  // f32 partial slabs
   } else {
+    od_mfma_results_ready();
     e8_epilogue_direct<MT>(p, acc, m0 + wr * WROWS, n0 + wc * 64, l15, lq);
   }
   if (DBG & 32) {

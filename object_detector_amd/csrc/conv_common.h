@@ -38,6 +38,23 @@ static __device__ __forceinline__ float od_expm1_fast(float v) {
   return v > -0.25f ? poly : __expf(v) - 1.f;
 }
 
+// v_permlane16_swap through inline asm (hipcc ROCm 7.2 folds repeated __builtin_amdgcn_permlane16_swap calls of an unrolled
+// loop into one).  The compiler's hazard recognizer does not see inside an asm statement: the caller must run
+// od_mfma_results_ready() once between the last MFMA that writes the swapped registers and the first swap (a VALU read
+// of an MFMA result needs up to 18 wait states); the s_nop pair here covers VALU-write -> permlane-read.
+static __device__ __forceinline__ void od_permlane16_swap(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+static __device__ __forceinline__ void od_mfma_results_ready() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// LeakyReLU with a slope in [0, 1] (od_conv2d_fwd validates it): max(v, alpha * v) is the same function as the select,
+// one v_mul + one v_max instead of compare + multiply + select.
+static __device__ __forceinline__ float od_leaky(float v, float alpha) { return fmaxf(v, v * alpha); }
+
 template <int N>
 static __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -135,7 +152,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvKP& p, char* smem
         for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
         if (p.act == OD_ACT_LEAKY) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+          for (int e = 0; e < 8; ++e) v[e] = od_leaky(v[e], p.alpha);
         } else if (p.act == OD_ACT_ELU) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : p.alpha * od_expm1_fast(v[e]);

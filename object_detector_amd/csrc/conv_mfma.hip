@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void od_conv_finish(ConvKP p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       v[e] = v[e] * p.scale[n + e] + p.bias[n + e];
-      if (p.act == OD_ACT_LEAKY) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+      if (p.act == OD_ACT_LEAKY) v[e] = od_leaky(v[e], p.alpha);
       else if (p.act == OD_ACT_ELU) v[e] = v[e] > 0.f ? v[e] : p.alpha * od_expm1_fast(v[e]);
     }
     const unsigned b = (unsigned)m / (unsigned)p.HoWo;
@@ -464,6 +464,7 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
              d->Cin, d->Cout);
   OD_REQUIRE(d->res_mode == OD_RES_NONE || d->res, "od_conv2d_fwd: res_mode set but res is null");
   OD_REQUIRE(d->act >= OD_ACT_LINEAR && d->act <= OD_ACT_ELU, "od_conv2d_fwd: bad act");
+  OD_REQUIRE(d->act != OD_ACT_LEAKY || (d->alpha >= 0.f && d->alpha <= 1.f), "od_conv2d_fwd: leaky slope must be in [0, 1]");
   const int pad = d->ksize / 2;
   const bool tconv = d->transposed != 0;
   if (tconv)

@@ -9,6 +9,7 @@ three levels write f32 straight into their slice of pred[B, P, 2+NC+4] (level-ma
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -80,6 +81,7 @@ class Net:
         self.level_hw = [(self.H // s, self.W // s) for s in (8, 16, 32)]
         self.P = sum(h * w for h, w in self.level_hw) * W.NUM_PRIORS
         self.tile_cfg = tile_cfg or {}
+        self.fuse_blocks = os.environ.get("OD_FUSE_BLOCKS", "1") != "0"  # fused residual blocks of the early stages
         self.splitk = True  # small-M layers (batch-1) may use split-K through a shared f32 slab workspace
         self._splitk_elems = 0
         self._splitk_descs = []
@@ -159,6 +161,27 @@ class Net:
                                  shape=(m, cout, k * k * cin)))
         return out, ho, wo
 
+    def _bneck(self, name, x, h, w, ch, act):
+        """one fused residual block (1x1 ch -> ch/2, 3x3 ch/2 -> ch, + x): od_bottleneck_fwd"""
+        w1, s1, b1 = self._dev[name + ".a"]
+        w3, s3, b3 = self._dev[name + ".b"]
+        out = self._buf(h, w, ch)
+        d = _lib.BneckDesc()
+        d.x, d.out = x.data_ptr(), out.data_ptr()
+        d.w1, d.scale1, d.bias1 = w1.data_ptr(), s1.data_ptr(), b1.data_ptr()
+        d.w3, d.scale3, d.bias3 = w3.data_ptr(), s3.data_ptr(), b3.data_ptr()
+        d.B, d.H, d.W, d.C = self.B, h, w, ch
+        d.act, d.alpha = _lib.ACT_ENUM[act[0] if act else None], float(act[1]) if act else 0.0
+        op = _lib.PlanOp()
+        op.kind = _lib.OD_OP_BNECK
+        op.bneck = d
+        self.ops.append(op)
+        m = self.B * h * w
+        self.op_info.append(dict(name=name, flops=2.0 * m * (ch * (ch // 2) + 9 * (ch // 2) * ch),
+                                 bytes=float(2 * m * ch * 2 + (ch * ch // 2 + 9 * ch * ch // 2) * 2),
+                                 shape=(m, ch, 10 * (ch // 2))))
+        return out
+
     def _build(self, bact, hact):
         B, H, Wd = self.B, self.H, self.W
         # first layer (uint8 in)
@@ -180,6 +203,9 @@ class Net:
         for si, (n, ch) in enumerate(W.STAGES, start=1):
             x, h, w = self._conv(f"b.down{si}", x, h, w, cin, ch, 3, 2, bact)
             for r in range(n):
+                if self.fuse_blocks and self.lib.od_bottleneck_supported(h, w, ch):
+                    x = self._bneck(f"b.s{si}.{r}", x, h, w, ch, bact)
+                    continue
                 t, _, _ = self._conv(f"b.s{si}.{r}.a", x, h, w, ch, ch // 2, 1, 1, bact)
                 x, _, _ = self._conv(f"b.s{si}.{r}.b", t, h, w, ch // 2, ch, 3, 1, bact, res=x,
                                      res_mode=_lib.OD_RES_SAME)

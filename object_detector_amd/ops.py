@@ -52,6 +52,34 @@ def conv2d(x: torch.Tensor, w_ohwi: np.ndarray, scale: np.ndarray, bias: np.ndar
     return out
 
 
+def bottleneck(x: torch.Tensor, w1_ohwi: np.ndarray, scale1, bias1, w3_ohwi: np.ndarray, scale3, bias3, act="leaky",
+               alpha=0.1):
+    """Fused residual block x + act(bn3(conv3x3(act(bn1(conv1x1(x)))))): x f16 [B,H,W,C] -> f16 [B,H,W,C]."""
+    ctx = _ctx(x)
+    assert x.dtype == torch.float16 and x.is_contiguous()
+    B, H, Wd, Cc = x.shape
+    assert w1_ohwi.shape == (Cc // 2, 1, 1, Cc) and w3_ohwi.shape == (Cc, 3, 3, Cc // 2)
+    keep = []
+
+    def dev(a):
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(x.device)
+        keep.append(t)
+        return t
+    w1p, w3p = dev(pack_conv_weight(w1_ohwi)), dev(pack_conv_weight(w3_ohwi))
+    out = torch.empty_like(x)
+    d = _lib.BneckDesc()
+    d.x, d.out, d.w1, d.w3 = x.data_ptr(), out.data_ptr(), w1p.data_ptr(), w3p.data_ptr()
+    d.scale1 = dev(pad_vec(np.asarray(scale1, np.float32), w1p.shape[0])).data_ptr()
+    d.bias1 = dev(pad_vec(np.asarray(bias1, np.float32), w1p.shape[0])).data_ptr()
+    d.scale3 = dev(pad_vec(np.asarray(scale3, np.float32), w3p.shape[0])).data_ptr()
+    d.bias3 = dev(pad_vec(np.asarray(bias3, np.float32), w3p.shape[0])).data_ptr()
+    d.B, d.H, d.W, d.C = B, H, Wd, Cc
+    d.act, d.alpha = _lib.ACT_ENUM[act], float(alpha)
+    _lib.check(ctx.lib.od_bottleneck_fwd(ctx.handle, C.byref(d), _stream_ptr()), "od_bottleneck_fwd")
+    torch.cuda.current_stream().synchronize()  # the packed weights above are temporaries
+    return out
+
+
 def conv_first(x_u8: torch.Tensor, w_ohwi: np.ndarray, scale, bias, act="leaky", alpha=0.1):
     ctx = _ctx(x_u8)
     assert x_u8.dtype == torch.uint8 and x_u8.is_contiguous()
