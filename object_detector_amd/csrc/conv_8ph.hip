@@ -481,7 +481,7 @@ struct E8Entry {
 #define OD_E8(MF1)                                                                                        \
   {                                                                                                       \
     32 * (4 + MF1), (const void*)&od_conv_8ph<1, MF1>, (const void*)&od_conv_8ph<3, MF1>,                 \
-        "od_conv_8ph<1, " #MF1 ">", "od_conv_8ph<3, " #MF1 ">"                                            \
+        "od_conv_8ph<1, " #MF1 ", 0, 1>", "od_conv_8ph<3, " #MF1 ", 0, 1>"                                          \
   }
 const E8Entry g_e8[] = {OD_E8(4), OD_E8(3), OD_E8(2), OD_E8(1)};  // BM = 256, 224, 192, 160
 const void* const g_e8_dbg[][2] = {{(const void*)&od_conv_8ph<3, 4, 1>, "od_conv_8ph<3, 4, dbg1>"},

@@ -427,7 +427,7 @@ extern "C" int od_bottleneck_supported(int H, int W, int C) {
   return (C == 64 || C == 128) && H > 0 && W > 0 && (H % 16) == 0 && (W % 16) == 0;
 }
 
-const char* od_bottleneck_kernel_name(int C) { return C == 64 ? "od_bneck<64>" : "od_bneck<128>"; }
+const char* od_bottleneck_kernel_name(int C) { return C == 64 ? "od_bneck<64, 0>" : "od_bneck<128, 0>"; }
 
 extern "C" int od_bottleneck_fwd(od_ctx* ctx, const od_bneck_desc* d, void* stream) {
   OD_REQUIRE(ctx && d, "od_bottleneck_fwd: null ctx/desc");
