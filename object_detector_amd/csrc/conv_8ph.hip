@@ -2,20 +2,21 @@
 //
 // The 128x128 kernels of conv_mfma.hip move 15.6 KB from L2 into LDS per MFLOP and pay one barrier per 32 MFMAs per
 // wave; they top out at ~35 % of the dense f16 MFMA peak.  This kernel halves the bytes per flop
-// (BM x 256 output tile, BM = 160..256) and runs the two waves of every SIMD half a phase apart, so that one of them is
-// always inside a 16-MFMA cluster while its partner issues LDS reads and the LDS-DMA of a later K tile:
+// (BM x 256 output tile, BM = 160..256) and skews the two waves of every SIMD by half a phase, so that one of them is
+// inside a 16-MFMA cluster while its partner issues LDS reads and the LDS-DMA of a later K tile:
 //
-//   waves 0-3 (wave row 0) and waves 4-7 (wave row 1) own (BM/2) x 64 output sub-tiles; waves 4-7 run one s_barrier
-//   behind waves 0-3 for the whole main loop.
-//   Per 64-deep K tile the wave does 4 phases = the 4 quadrants of its sub-tile, register operands reused:
+//   waves 0-3 (wave row 0) and waves 4-7 (wave row 1) own (BM/2) x 64 output sub-tiles.
+//   Per 64-deep K tile a wave does 4 phases = the 4 quadrants of its sub-tile, register operands reused:
 //     p0: read A-lo (4 m-frags) + B-lo (2 n-frags)   MFMA A-lo x B-lo     stage B-hi of tile t+1
 //     p1: read B-hi                                  MFMA A-lo x B-hi     stage A-hi of tile t+1
 //     p2: read A-hi (MF1 m-frags)                    MFMA A-hi x B-hi     stage A-lo of tile t+2
 //     p3: (B-lo still in registers)                  MFMA A-hi x B-lo     stage B-lo of tile t+2
-//   phase = { ds_read_b128 ..., 2 x global_load_lds_dwordx4, counted s_waitcnt vmcnt, s_barrier, 16 MFMA, s_barrier }.
+//   load part = { ds_read_b128 ..., 2 x buffer_load_dwordx4 ... lds, counted s_waitcnt vmcnt }, MFMA part = 16 MFMAs.
+//   ONE s_barrier per phase: wave row 0 runs { load part, MFMA part } between two barriers, wave row 1 runs { MFMA part of
+//   the previous phase, load part } -- the skew is in program order, not in barrier count.
 //   LDS = 2 K-tile buffers x 4 regions (A-lo, A-hi, B-lo, B-hi; 128 rows x 128 B each, chunk ^ (row & 7) swizzle on
-//   the DMA source side) = 128 KiB.  A region is re-staged no earlier than two phases after its last read, and read no
-//   earlier than one phase after the counted wait (+ barrier) that retires its DMA -- for both wave groups.
+//   the DMA source side) = 128 KiB.  A region is re-staged no earlier than two intervals after its last read, and read no
+//   earlier than one interval after the counted wait (+ barrier) that retires its DMA -- for both wave rows.
 //   vmcnt never drains to 0 in the steady state: every wait leaves the 4 youngest stages (8 DMAs per wave) in flight.
 //
 // A operand = activations gathered im2col-free (per-lane source = shifted input pixel or the zero page), B operand =

@@ -6,14 +6,16 @@
 //
 // One workgroup (8 waves) owns a 16x16-pixel output tile:
 //   1. LDS-DMA: the 18x18 input window (zeros outside the image), the 1x1 weights and the 3x3 weights
-//      (C = 64: all 9 taps resident; C = 128: tap 0, the other taps stream through a 2-deep ring during step 3)
+//      (C = 64: all 9 taps resident, persistent workgroups with two window buffers; C = 128: tap 0, the other taps
+//      stream through a 7-slot ring during step 3, see BneckCfg)
 //   2. producer: t = act(s1 * (x_window . w1) + b1) for the 324 window pixels on MFMA (21 m-fragments over 8 waves),
 //      rounded ONCE to f16 and written to the LDS window of t; window pixels outside the image are written as 0,
 //      which is exactly the zero padding the 3x3 convolution sees in the unfused network
 //   3. consumer: the 3x3 convolution reads its A fragments straight out of that window (fragment = one 16-pixel tile
-//      row, shifted by the tap), waves 4 (tile rows) x 2 (channels)
+//      row, shifted by the tap; taps column by column so that 6 fragments serve 3 taps), waves 4 (tile rows) x 2 (channels)
 //   4. epilogue from the accumulators: v_permlane16_swap gives every lane 8 consecutive channels of its pixel;
-//      scale/bias/activation in f32, + residual read from the x window still in LDS, one rounding, 16-byte stores.
+//      scale/bias/activation in f32, + residual from the x window (LDS, or registers at C = 128), one rounding,
+//      16-byte stores.
 // LDS rows are chunk-swizzled on the DMA source side (conflict-free ds_read_b128 for every tap shift, brute-forced
 // against the gfx950 lane-group bank model): 256-B rows chunk ^ ((row & 7) << 1), 128-B rows chunk ^ (row & 7),
 // 64-B rows chunk ^ (3 * ((row >> 2) & 1)).
