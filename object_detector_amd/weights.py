@@ -85,3 +85,62 @@ def load(path):
         params = {k: z[k] for k in z.files if not k.startswith("__meta__.")}
         meta = {k[len("__meta__."):]: z[k] for k in z.files if k.startswith("__meta__.")}
     return params, meta
+
+
+# ---- Darknet backbone import --------------------------------------------------------------
+# The reference's base network is "Darknet53 (YOLOv3's base network)" (docs/MODEL.md:15-17); its public pre-trained file is
+# `darknet53.conv.74`.  Layout of a Darknet weights file [published format, pjreddie/darknet `parser.c::load_weights`]:
+#   int32 major, minor, revision; then `seen` as int64 if major*10 + minor >= 2 else int32;
+#   then per convolutional layer, in network order, float32 little endian:
+#       batch-normalised layer:  beta[Cout], gamma[Cout], running_mean[Cout], running_var[Cout], w[Cout][Cin][k][k]
+#       plain layer:             bias[Cout], w[Cout][Cin][k][k]
+# Darknet's BatchNorm epsilon is 1e-6 (blas.c::normalize_cpu uses sqrt(var) + .000001f); this build folds BN with
+# BN_EPS, so the import rewrites var so that gamma / sqrt(var' + BN_EPS) equals Darknet's gamma / (sqrt(var) + 1e-6).
+DARKNET_BN_EPS = 1e-6
+
+
+def backbone_specs():
+    return [s for s in layer_specs() if s[0].startswith("b.")]
+
+
+def load_darknet_backbone(path, params=None):
+    """Read the 52 backbone convolutions of a Darknet `darknet53.conv.74`-style file (a LOCAL file, never downloaded) into
+    `params` (a fresh random-init detector if None).  Returns (params, n_floats_read).  Raises ValueError when the
+    file is shorter than the backbone needs."""
+    raw = np.fromfile(pathlib.Path(path), dtype=np.uint8)
+    if raw.size < 16:
+        raise ValueError(f"{path}: not a Darknet weights file (too short)")
+    major, minor, _rev = np.frombuffer(raw[:12].tobytes(), dtype="<i4")
+    off = 12 + (8 if int(major) * 10 + int(minor) >= 2 else 4)
+    data = np.frombuffer(raw[off:off + (raw.size - off) // 4 * 4].tobytes(), dtype="<f4")
+    params = dict(random_init() if params is None else params)
+    pos = 0
+
+    def take(n):
+        nonlocal pos
+        if pos + n > data.size:
+            raise ValueError(f"{path}: ends after {data.size} floats; the Darknet53 backbone needs more")
+        out = data[pos:pos + n]
+        pos += n
+        return out
+
+    for name, cin, cout, k, _s, _bn in backbone_specs():
+        beta, gamma, mean, var = (take(cout).astype(np.float32) for _ in range(4))
+        w = take(cout * cin * k * k).reshape(cout, cin, k, k)
+        params[name + ".w"] = np.ascontiguousarray(w.transpose(0, 2, 3, 1)).astype(np.float32)  # OIHW -> OHWI
+        params[name + ".gamma"], params[name + ".beta"], params[name + ".mean"] = gamma, beta, mean
+        sd = np.sqrt(np.maximum(var, 0.0)) + np.float32(DARKNET_BN_EPS)
+        params[name + ".var"] = (sd * sd - np.float32(BN_EPS)).astype(np.float32)  # may be < 0: only var + BN_EPS is used
+    return params, pos
+
+
+def save_darknet_backbone(path, params, major=0, minor=2, revision=0, seen=0):
+    """Inverse of load_darknet_backbone (round-trip tests; export for Darknet-side comparison)."""
+    chunks = [np.asarray([major, minor, revision], "<i4").tobytes(),
+              np.asarray([seen], "<i8" if major * 10 + minor >= 2 else "<i4").tobytes()]
+    for name, _cin, _cout, _k, _s, _bn in backbone_specs():
+        sd = np.sqrt(params[name + ".var"].astype(np.float64) + BN_EPS) - DARKNET_BN_EPS
+        for v in (params[name + ".beta"], params[name + ".gamma"], params[name + ".mean"], (sd * sd)):
+            chunks.append(np.asarray(v, "<f4").tobytes())
+        chunks.append(np.ascontiguousarray(params[name + ".w"].transpose(0, 3, 1, 2)).astype("<f4").tobytes())
+    pathlib.Path(path).write_bytes(b"".join(chunks))

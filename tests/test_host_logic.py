@@ -200,3 +200,29 @@ def test_tk_surface_matches_reference_scripts():
     def f(v):
         return v + 1
     assert f(1) == 2
+
+
+def test_darknet_backbone_import_roundtrip(tmp_path):
+    """weights.load_darknet_backbone reads the published Darknet layout (header, then beta/gamma/mean/var/w per conv,
+    OIHW) -- checked by writing a file in that layout from known parameters and reading it back.  The real
+    darknet53.conv.74 is not available offline: the folded scale/bias must survive the BatchNorm-epsilon rewrite."""
+    from object_detector_amd import weights as W
+    src = W.random_init(seed=7)
+    p = tmp_path / "d53.weights"
+    W.save_darknet_backbone(p, src)
+    n_expected = sum(4 * cout + cout * cin * k * k for _n, cin, cout, k, _s, _b in W.backbone_specs())
+    # 40 620 640 floats + 20 header bytes = 162 482 580 bytes, the size of the published darknet53.conv.74
+    assert n_expected == 40_620_640 and p.stat().st_size == 162_482_580
+    got, n = W.load_darknet_backbone(p, W.random_init(seed=9))
+    assert n == n_expected
+    for name, *_ in W.backbone_specs():
+        np.testing.assert_array_equal(got[name + ".w"], src[name + ".w"])
+        s0, b0 = W.fold_bn(src, name)
+        s1, b1 = W.fold_bn(got, name)
+        np.testing.assert_allclose(s1, s0, rtol=2e-6)
+        np.testing.assert_allclose(b1, b0, rtol=2e-5, atol=1e-6)
+    assert np.array_equal(got["h.out.w"], W.random_init(seed=9)["h.out.w"])  # head untouched
+    with open(p, "r+b") as f:
+        f.truncate(10_000)
+    with pytest.raises(ValueError):
+        W.load_darknet_backbone(p)
