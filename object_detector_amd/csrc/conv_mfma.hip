@@ -402,6 +402,12 @@ const TileCfg g_cfgs[] = {
     OD_CFG(256, 256, 64, 2, 4, 4, 4),    // 21: 16 waves (4 per SIMD, wave tile 64x64), 128 KiB, 1 WG/CU
     OD_CFG(256, 256, 32, 4, 4, 4, 4),    // 22: same, 32-deep steps, 4-deep ring
     OD_CFG(256, 256, 32, 3, 4, 4, 4),    // 23: 3-deep ring (96 KiB)
+    OD_CFG(64, 64, 64, 4, 2, 2, 2),      // 24: deep rings for the short-K 1x1 layers (cold L2: latency, not bandwidth)
+    OD_CFG(64, 128, 64, 3, 2, 2, 2),     // 25: 72 KiB, 2 WG/CU
+    OD_CFG(64, 128, 64, 4, 2, 2, 2),     // 26: 96 KiB, 1 WG/CU
+    OD_CFG_S(64, 128, 64, 3, 2, 2, 4),   // 27: specialised, 72 KiB
+    OD_CFG_S(64, 128, 64, 4, 2, 2, 2),   // 28: specialised, 96 KiB
+    OD_CFG(128, 128, 64, 4, 2, 2, 1),    // 29: 128 KiB
 };
 constexpr int kNumCfgs = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
@@ -411,9 +417,13 @@ int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize, bool e8_ok)
   const bool spec_ok = (Cin % 64) == 0;  // wave-specialised kernels are tap-uniform only
   if (Cout <= 64) return (ksize == 3 && od_ceil_div(M, 128) >= 8 * cus) ? 1 : 3;
   const long t128 = (long)od_ceil_div(M, 128) * od_ceil_div(Cout, 128);
+  // small-M layers, measured IN the network (scripts/sweep_net_cfg.py, profiles/r01/conv_innet_sweep.txt): their input
+  // was just written by the previous kernel, every first touch misses L2, so ring depth matters more than in a
+  // back-to-back microbenchmark -- 3-deep specialised 64x128 (27) for M <= 16 k, 4-deep 64x64 (24) for long-K 1x1 at M <= 4 k
   if (ksize == 1) {
-    if (!spec_ok || M <= 4096) return 3;
-    if (M <= 16384) return 17;
+    if (!spec_ok) return 3;
+    if (M <= 4096) return (M >= 2048 && Cin >= 512) ? 24 : 3;
+    if (M <= 16384) return 27;
     if (Cout < 256) return 3;
     // wide 1x1 (neck laterals): fall through to the 128x128 / 8-wave comparison below
     if (t128 < cus) return 13;
@@ -438,7 +448,7 @@ int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize, bool e8_ok)
     }
     return pick;
   }
-  if (Cout <= 256) return M <= 4096 ? 3 : 17;      // few, narrow tiles (prediction module on the coarse levels)
+  if (Cout <= 256) return M < 2048 ? 3 : 27;       // few, narrow tiles (neck / prediction module on the coarse levels)
   return 14;                                       // few tiles, long K: one deep-ring workgroup per CU
 }
 

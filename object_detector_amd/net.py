@@ -80,7 +80,10 @@ class Net:
         self.C = 2 + self.num_classes + 4
         self.level_hw = [(self.H // s, self.W // s) for s in (8, 16, 32)]
         self.P = sum(h * w for h, w in self.level_hw) * W.NUM_PRIORS
-        self.tile_cfg = tile_cfg or {}
+        self.tile_cfg = dict(tile_cfg or {})
+        for item in filter(None, os.environ.get("OD_TILE_CFG", "").split(",")):  # tuning: "b.s3=24,n.lat=25" (name prefixes)
+            pat, cfg = item.split("=")
+            self.tile_cfg[pat] = int(cfg)
         self.fuse_blocks = os.environ.get("OD_FUSE_BLOCKS", "1") != "0"  # fused residual blocks of the early stages
         self.splitk = True  # small-M layers (batch-1) may use split-K through a shared f32 slab workspace
         self._splitk_elems = 0
@@ -145,6 +148,10 @@ class Net:
         d.out_dtype = _lib.OD_DT_F32 if out_f32 else _lib.OD_DT_F16
         d.out_batch_stride, d.out_pix_stride = obs, ops
         d.tile_cfg = self.tile_cfg.get(name, -1)
+        for pat, cfg in self.tile_cfg.items():  # patterns "prefix*suffix", e.g. "b.s3*a" = the 1x1 convs of stage 3
+            pre, star, suf = pat.partition("*")
+            if star and name.startswith(pre) and name.endswith(suf):
+                d.tile_cfg = cfg
         m = self.B * ho * wo
         if self.splitk and m * cout <= (1 << 22):  # candidates only; the library decides per layer
             self._splitk_elems = max(self._splitk_elems, m * cout)

@@ -28,7 +28,7 @@ def _ref(x, w, scale, bias, stride, act, alpha, res=None, up2=False):
     return y
 
 
-NIG, NWIN = 24, 12   # implicit-GEMM tile configs 0..23, LDS-window configs 24..35, persistent window kernel 36
+NIG, NWIN = 30, 12   # implicit-GEMM tile configs 0..29, LDS-window configs 30..41, persistent window kernel 42
 NPW = NIG + NWIN
 SPEC0 = 13            # first wave-specialised implicit-GEMM config
 
@@ -116,9 +116,9 @@ def test_conv_matches_oracle(cuda, case):
     (1, 20, 20, 256, 512, 3, 2, "leaky", "none", 2, 0),     # stride 2
     (1, 10, 10, 256, 208, 3, 1, None, "none", 3, 5),        # ragged Cout, generic-capable config
     (2, 6, 6, 40, 72, 3, 1, "leaky", "same", 3, 3),         # non-uniform taps (Cin = 40) + split
-    (1, 10, 10, 512, 1024, 3, 1, "leaky", "same", 37, 6),   # 8-wave kernel, 12 K tiles per split
-    (2, 10, 10, 512, 304, 3, 1, "elu", "none", 39, 5),      # BM = 192, uneven split (72 tiles / 5)
-    (1, 20, 20, 512, 256, 1, 1, "elu", "up2", 38, 4),       # 1x1, 2 K tiles per split
+    (1, 10, 10, 512, 1024, 3, 1, "leaky", "same", NIG + 13, 6),   # 8-wave kernel, 12 K tiles per split
+    (2, 10, 10, 512, 304, 3, 1, "elu", "none", NIG + 15, 5),      # BM = 192, uneven split (72 tiles / 5)
+    (1, 20, 20, 512, 256, 1, 1, "elu", "up2", NIG + 14, 4),       # 1x1, 2 K tiles per split
 ], ids=str)
 def test_conv_split_k(cuda, case):
     """split-K path: per-split f32 slabs + finish kernel summing them in a fixed order (bit-reproducible)."""
