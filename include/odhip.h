@@ -115,6 +115,27 @@ typedef struct od_bneck_desc {
 int od_bottleneck_supported(int H, int W, int C);
 int od_bottleneck_fwd(od_ctx* ctx, const od_bneck_desc* d, void* stream);
 
+/* K3+K1 fused stem: the first two Darknet53 layers (uint8 image -> 3x3 conv 3->32 -> 3x3 stride-2 conv 32->64, each with
+ * folded BatchNorm + activation) in one launch; the 32-channel full-resolution tensor stays on chip.
+ *   x u8 [B,H,W,3]; w0 f16 [32][32] as od_conv_first_fwd takes it; w3 = packed weights of the stride-2 conv as
+ *   od_conv2d_fwd takes them; out f16 [B,H/2,W/2,64].  H and W multiples of 32 (od_stem_supported).
+ * Replaces the preprocess + first two Conv2D layers of predict (reference voc_validate.py:27; docs/MODEL.md:15-17). */
+typedef struct od_stem_desc {
+  const uint8_t* x;
+  const void* w0;
+  const float* scale0;
+  const float* bias0;
+  const void* w3;
+  const float* scale3;
+  const float* bias3;
+  void* out;
+  int32_t B, H, W;
+  int32_t act; /* OD_ACT_*, both convolutions */
+  float alpha;
+} od_stem_desc;
+int od_stem_supported(int H, int W);
+int od_stem_fwd(od_ctx* ctx, const od_stem_desc* d, void* stream);
+
 /* K3: first layer, uint8 RGB image in, 3x3 stride-1 conv 3->Cout (Cout = 32), input normalisation folded
  * into scale.  x u8 [B,H,W,3]; w f16 packed [Cout][32] (k = (dy*3+dx)*3 + c, k >= 27 zero);
  * out f16 [B,H,W,Cout].  Replaces the image preprocess + first Conv2D of predict (voc_validate.py:27). */
@@ -261,12 +282,14 @@ int od_augment_batch(od_ctx* ctx, const uint8_t* src, const void* params, uint8_
 #define OD_OP_CONV 1
 #define OD_OP_CONV_FIRST 2
 #define OD_OP_BNECK 3
+#define OD_OP_STEM 4
 
 typedef struct od_plan_op {
   int32_t kind; /* OD_OP_* */
   int32_t pad_;
   od_conv_desc conv; /* OD_OP_CONV; OD_OP_CONV_FIRST uses x(u8), w, scale, bias, out, B,H,W,Cout,act,alpha */
   od_bneck_desc bneck; /* OD_OP_BNECK */
+  od_stem_desc stem;   /* OD_OP_STEM */
 } od_plan_op;
 
 typedef struct od_plan od_plan;

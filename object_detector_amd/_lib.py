@@ -15,7 +15,7 @@ LIB_PATH = _HERE / "libodhip.so"
 OD_ACT_LINEAR, OD_ACT_LEAKY, OD_ACT_ELU = 0, 1, 2
 OD_RES_NONE, OD_RES_SAME, OD_RES_UP2 = 0, 1, 2
 OD_DT_F16, OD_DT_F32 = 0, 1
-OD_OP_CONV, OD_OP_CONV_FIRST, OD_OP_BNECK = 1, 2, 3
+OD_OP_CONV, OD_OP_CONV_FIRST, OD_OP_BNECK, OD_OP_STEM = 1, 2, 3, 4
 
 ACT_ENUM = {None: OD_ACT_LINEAR, "linear": OD_ACT_LINEAR, "leaky": OD_ACT_LEAKY, "elu": OD_ACT_ELU}
 
@@ -49,8 +49,16 @@ class BneckDesc(C.Structure):
     ]
 
 
+class StemDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w0", C.c_void_p), ("scale0", C.c_void_p), ("bias0", C.c_void_p),
+        ("w3", C.c_void_p), ("scale3", C.c_void_p), ("bias3", C.c_void_p), ("out", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float),
+    ]
+
+
 class PlanOp(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("pad_", C.c_int32), ("conv", ConvDesc), ("bneck", BneckDesc)]
+    _fields_ = [("kind", C.c_int32), ("pad_", C.c_int32), ("conv", ConvDesc), ("bneck", BneckDesc), ("stem", StemDesc)]
 
 
 class OdError(RuntimeError):
@@ -68,6 +76,8 @@ _PROTOS = {
     "od_conv_weight_dims": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "od_conv_num_tile_cfgs": (C.c_int, []),
     "od_conv2d_fwd": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_void_p]),
+    "od_stem_supported": (C.c_int, [C.c_int, C.c_int]),
+    "od_stem_fwd": (C.c_int, [C.c_void_p, C.POINTER(StemDesc), C.c_void_p]),
     "od_bottleneck_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "od_bottleneck_fwd": (C.c_int, [C.c_void_p, C.POINTER(BneckDesc), C.c_void_p]),
     "od_conv_first_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -66,6 +66,7 @@ static int run_op(od_plan* pl, int i, hipStream_t s) {
                              c.alpha, s);
   }
   if (op.kind == OD_OP_BNECK) return od_bottleneck_fwd(pl->ctx, &op.bneck, s);
+  if (op.kind == OD_OP_STEM) return od_stem_fwd(pl->ctx, &op.stem, s);
   od_set_error("od_plan: unknown op kind %d at %d", op.kind, i);
   return OD_ERR_INVALID;
 }
@@ -87,6 +88,13 @@ extern "C" int od_plan_create(od_ctx* ctx, const od_plan_op* ops, int n_ops, od_
       pl->names[i] = nm;
     } else if (ops[i].kind == OD_OP_CONV_FIRST) {
       pl->names[i] = od_conv_first_kernel_name();
+    } else if (ops[i].kind == OD_OP_STEM) {
+      if (!od_stem_supported(ops[i].stem.H, ops[i].stem.W)) {
+        od_set_error("od_plan_create: op %d: fused stem needs H, W multiples of 32 (got %dx%d)", i, ops[i].stem.H, ops[i].stem.W);
+        delete pl;
+        return OD_ERR_INVALID;
+      }
+      pl->names[i] = od_stem_kernel_name();
     } else if (ops[i].kind == OD_OP_BNECK) {
       if (!od_bottleneck_supported(ops[i].bneck.H, ops[i].bneck.W, ops[i].bneck.C)) {
         od_set_error("od_plan_create: op %d: fused block unsupported for C=%d, %dx%d", i, ops[i].bneck.C, ops[i].bneck.H,

@@ -54,3 +54,4 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
                        bool dry_run);
 const char* od_conv_first_kernel_name();
 const char* od_bottleneck_kernel_name(int C);
+const char* od_stem_kernel_name();

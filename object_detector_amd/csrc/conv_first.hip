@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int TH = 8, TW = 32;               // output pixels per workgroup
+constexpr int TH = 32, TW = 32;              // output pixels per workgroup (TH = 8 / 16 / 32 measured: 69.7 / 61.4 / 58.1 us)
 constexpr int LW = TW + 2, LH = TH + 2;      // halo tile
 constexpr int ROWB = LW * 3;                 // contiguous source bytes per halo row
 
@@ -58,9 +58,9 @@ __global__ __launch_bounds__(256) void od_conv_first(const uint8_t* __restrict__
   }
   __syncthreads();
 
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int yy = wave * 2 + (mt >> 1);
+#pragma unroll 4
+  for (int mt = 0; mt < TH / 2; ++mt) {
+    const int yy = wave * (TH / 4) + (mt >> 1);
     const int xx = (mt & 1) * 16 + l15;
     const uint8_t* pbase = tile + (yy * LW + xx) * 4;
     f16x8 xf;
@@ -112,14 +112,15 @@ extern "C" int od_conv_first_fwd(od_ctx* ctx, const uint8_t* x, const void* w, c
 // Tiny output (32 x 27), huge reduction: VALU kernel, one 8x32-pixel tile per workgroup, halo in LDS, per-workgroup
 // partial sums reduced through LDS, one f32 atomic per (co, k) per workgroup.  No dX (the input is the image).
 namespace {
+constexpr int GTH = 8, GLH = GTH + 2;  // this kernel's own tile: 8 rows (one per 32-thread part) x 32 pixels
 __global__ __launch_bounds__(256) void od_conv_first_wgrad(const uint8_t* __restrict__ x, const f16* __restrict__ dz,
                                                            float* __restrict__ dw, int H, int W, float in_scale) {
-  __shared__ uint8_t tile[LH * LW * 4];
+  __shared__ uint8_t tile[GLH * LW * 4];
   __shared__ float red[8][32][28];
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, b = blockIdx.z;
-  for (int i = tid; i < LH * LW; i += 256) tile[i * 4 + 3] = 0;
-  for (int i = tid; i < LH * ROWB; i += 256) {
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * GTH, b = blockIdx.z;
+  for (int i = tid; i < GLH * LW; i += 256) tile[i * 4 + 3] = 0;
+  for (int i = tid; i < GLH * ROWB; i += 256) {
     const int r = i / ROWB, bt = i - r * ROWB;
     const int px = bt / 3, c = bt - px * 3;
     const int gy = y0 - 1 + r, gx = x0 - 1 + px;
@@ -163,7 +164,7 @@ extern "C" int od_conv_first_bwd_weight(od_ctx* ctx, const uint8_t* x, const voi
                                         int Cout, float in_scale, void* stream) {
   OD_REQUIRE(ctx && x && dz && dw && Cout == 32 && B > 0 && H > 0 && W > 0 && B <= 65535,
              "od_conv_first_bwd_weight: bad argument (Cout must be 32)");
-  dim3 grid(od_ceil_div(W, TW), od_ceil_div(H, TH), B);
+  dim3 grid(od_ceil_div(W, TW), od_ceil_div(H, GTH), B);
   hipLaunchKernelGGL(od_conv_first_wgrad, grid, dim3(256), 0, (hipStream_t)stream, x, (const f16*)dz, dw, H, W, in_scale);
   OD_CHECK_LAUNCH();
   return OD_OK;

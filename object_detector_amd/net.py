@@ -191,24 +191,48 @@ class Net:
 
     def _build(self, bact, hact):
         B, H, Wd = self.B, self.H, self.W
-        # first layer (uint8 in)
-        wt, sc, bi = self._dev["b.conv0"]
-        x = self._buf(H, Wd, 32)
-        d = _lib.ConvDesc()
-        d.x, d.w, d.scale, d.bias, d.out = self.input.data_ptr(), wt.data_ptr(), sc.data_ptr(), bi.data_ptr(), x.data_ptr()
-        d.B, d.H, d.W, d.Cin, d.Cout = B, H, Wd, 3, 32
-        d.ksize, d.stride = 3, 1
-        d.act, d.alpha = _lib.ACT_ENUM[bact[0]], float(bact[1])
-        op = _lib.PlanOp()
-        op.kind = _lib.OD_OP_CONV_FIRST
-        op.conv = d
-        self.ops.append(op)
-        self.op_info.append(dict(name="b.conv0", flops=2.0 * B * H * Wd * 32 * 27,
-                                 bytes=float(B * H * Wd * (3 + 64)), shape=(B * H * Wd, 32, 27)))
+        fuse_stem = self.fuse_blocks and self.lib.od_stem_supported(H, Wd)
+        if fuse_stem:
+            # first two layers in one launch (od_stem_fwd): uint8 in, f16 [B,H/2,W/2,64] out
+            w0, sc0, bi0 = self._dev["b.conv0"]
+            w3, sc3, bi3 = self._dev["b.down1"]
+            x = self._buf(H // 2, Wd // 2, 64)
+            d = _lib.StemDesc()
+            d.x, d.out = self.input.data_ptr(), x.data_ptr()
+            d.w0, d.scale0, d.bias0 = w0.data_ptr(), sc0.data_ptr(), bi0.data_ptr()
+            d.w3, d.scale3, d.bias3 = w3.data_ptr(), sc3.data_ptr(), bi3.data_ptr()
+            d.B, d.H, d.W = B, H, Wd
+            d.act, d.alpha = _lib.ACT_ENUM[bact[0]], float(bact[1])
+            op = _lib.PlanOp()
+            op.kind = _lib.OD_OP_STEM
+            op.stem = d
+            self.ops.append(op)
+            m1 = B * (H // 2) * (Wd // 2)
+            self.op_info.append(dict(name="b.stem", flops=2.0 * B * H * Wd * 32 * 27 + 2.0 * m1 * 64 * 288,
+                                     bytes=float(B * H * Wd * 3 + m1 * 64 * 2), shape=(m1, 64, 288 + 27)))
+        else:
+            # first layer (uint8 in)
+            wt, sc, bi = self._dev["b.conv0"]
+            x = self._buf(H, Wd, 32)
+            d = _lib.ConvDesc()
+            d.x, d.w, d.scale, d.bias, d.out = (self.input.data_ptr(), wt.data_ptr(), sc.data_ptr(), bi.data_ptr(),
+                                                x.data_ptr())
+            d.B, d.H, d.W, d.Cin, d.Cout = B, H, Wd, 3, 32
+            d.ksize, d.stride = 3, 1
+            d.act, d.alpha = _lib.ACT_ENUM[bact[0]], float(bact[1])
+            op = _lib.PlanOp()
+            op.kind = _lib.OD_OP_CONV_FIRST
+            op.conv = d
+            self.ops.append(op)
+            self.op_info.append(dict(name="b.conv0", flops=2.0 * B * H * Wd * 32 * 27,
+                                     bytes=float(B * H * Wd * (3 + 64)), shape=(B * H * Wd, 32, 27)))
         h, w, cin = H, Wd, 32
         taps = []
         for si, (n, ch) in enumerate(W.STAGES, start=1):
-            x, h, w = self._conv(f"b.down{si}", x, h, w, cin, ch, 3, 2, bact)
+            if si == 1 and fuse_stem:
+                h, w = h // 2, w // 2
+            else:
+                x, h, w = self._conv(f"b.down{si}", x, h, w, cin, ch, 3, 2, bact)
             for r in range(n):
                 if self.fuse_blocks and self.lib.od_bottleneck_supported(h, w, ch):
                     x = self._bneck(f"b.s{si}.{r}", x, h, w, ch, bact)

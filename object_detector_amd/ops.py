@@ -80,6 +80,33 @@ def bottleneck(x: torch.Tensor, w1_ohwi: np.ndarray, scale1, bias1, w3_ohwi: np.
     return out
 
 
+def stem(x_u8: torch.Tensor, w0_ohwi: np.ndarray, scale0, bias0, w3_ohwi: np.ndarray, scale3, bias3, act="leaky", alpha=0.1):
+    """Fused first two layers: u8 [B,H,W,3] -> f16 [B,H/2,W/2,64] (od_stem_fwd)."""
+    ctx = _ctx(x_u8)
+    assert x_u8.dtype == torch.uint8 and x_u8.is_contiguous()
+    B, H, Wd, _ = x_u8.shape
+    assert w0_ohwi.shape == (32, 3, 3, 3) and w3_ohwi.shape == (64, 3, 3, 32)
+    keep = []
+
+    def dev(a):
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(x_u8.device)
+        keep.append(t)
+        return t
+    w0p, w3p = dev(pack_first_weight(w0_ohwi)), dev(pack_conv_weight(w3_ohwi))
+    out = torch.empty((B, H // 2, Wd // 2, 64), dtype=torch.float16, device=x_u8.device)
+    d = _lib.StemDesc()
+    d.x, d.out, d.w0, d.w3 = x_u8.data_ptr(), out.data_ptr(), w0p.data_ptr(), w3p.data_ptr()
+    d.scale0 = dev(np.asarray(scale0, np.float32)).data_ptr()
+    d.bias0 = dev(np.asarray(bias0, np.float32)).data_ptr()
+    d.scale3 = dev(pad_vec(np.asarray(scale3, np.float32), w3p.shape[0])).data_ptr()
+    d.bias3 = dev(pad_vec(np.asarray(bias3, np.float32), w3p.shape[0])).data_ptr()
+    d.B, d.H, d.W = B, H, Wd
+    d.act, d.alpha = _lib.ACT_ENUM[act], float(alpha)
+    _lib.check(ctx.lib.od_stem_fwd(ctx.handle, C.byref(d), _stream_ptr()), "od_stem_fwd")
+    torch.cuda.current_stream().synchronize()
+    return out
+
+
 def conv_first(x_u8: torch.Tensor, w_ohwi: np.ndarray, scale, bias, act="leaky", alpha=0.1):
     ctx = _ctx(x_u8)
     assert x_u8.dtype == torch.uint8 and x_u8.is_contiguous()
