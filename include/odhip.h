@@ -239,6 +239,41 @@ int od_sgd_step(od_ctx* ctx, float* w, float* m, const float* g, long long n, fl
  * [Cin_pad][Kpad_t] (taps flipped, channels swapped); both destinations must be pre-zeroed once (padding) */
 int od_pack_weights(od_ctx* ctx, const float* w, void* w_fwd, void* w_bwd, int Cout, int Cin, int ksize, void* stream);
 
+/* Deterministic weight gradients: od_conv2d_bwd_weight_slabs writes the per-split partial sums as
+ * od_conv2d_bwd_weight_splits(...) dense f32 slabs [split][Cout][k*k*Cin] (plain stores, no atomics); one
+ * od_wgrad_reduce_multi launch per step then sums every layer's slabs in ascending order into the flat gradient buffer
+ * (`table` = DEVICE array; a layer shared by several pyramid levels lists all of their slabs). */
+typedef struct od_wgrad_red {
+  int64_t dw_offset; /* into the flat gradient buffer */
+  int64_t count;     /* Cout * k*k*Cin */
+  const float* slabs;
+  int32_t nslabs;
+  int32_t pad_;
+} od_wgrad_red;
+int od_conv2d_bwd_weight_splits(od_ctx* ctx, int B, int H, int W, int Cin, int Cout, int ksize, int stride);
+int od_conv2d_bwd_weight_slabs(od_ctx* ctx, const void* x, const void* dz, float* slabs, int B, int H, int W, int Cin,
+                               int Cout, int ksize, int stride, void* stream);
+int od_wgrad_reduce_multi(od_ctx* ctx, const od_wgrad_red* table, int nlayers, float* grads, void* stream);
+
+/* Multi-tensor forms (one launch for the whole parameter set instead of one per tensor -- ~240 launches per step):
+ *   od_sgd_step_multi: `segs` is a DEVICE array of od_sgd_seg over one flat f32 parameter / momentum / gradient buffer;
+ *   od_pack_weights_multi: `layers` is a DEVICE array of od_pack_layer (w_offset into the same flat buffer). */
+typedef struct od_sgd_seg {
+  int64_t offset; /* first element of the segment in the flat buffers */
+  int64_t count;
+  float lr;
+  float weight_decay;
+} od_sgd_seg;
+typedef struct od_pack_layer {
+  int64_t w_offset; /* master weights f32 [Cout][k*k*Cin] inside the flat parameter buffer */
+  void* w_fwd;      /* f16 [Cout_pad][Kpad] */
+  void* w_bwd;      /* f16 [Cin_pad][Kpad_t] or NULL */
+  int32_t Cout, Cin, ksize, pad_;
+} od_pack_layer;
+int od_sgd_step_multi(od_ctx* ctx, float* w, float* m, const float* g, const od_sgd_seg* segs, int nseg, float momentum,
+                      float inv_loss_scale, void* stream);
+int od_pack_weights_multi(od_ctx* ctx, const float* w, const od_pack_layer* layers, int nlayers, void* stream);
+
 /* first layer's weight gradient: dw f32 [32][27] += dz^T . shifted(x_u8) * in_scale (no dX: the input is the image) */
 int od_conv_first_bwd_weight(od_ctx* ctx, const uint8_t* x, const void* dz, float* dw, int B, int H, int W, int Cout,
                              float in_scale, void* stream);

@@ -57,6 +57,20 @@ class StemDesc(C.Structure):
     ]
 
 
+class SgdSeg(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("count", C.c_int64), ("lr", C.c_float), ("weight_decay", C.c_float)]
+
+
+class WgradRed(C.Structure):
+    _fields_ = [("dw_offset", C.c_int64), ("count", C.c_int64), ("slabs", C.c_void_p), ("nslabs", C.c_int32),
+                ("pad_", C.c_int32)]
+
+
+class PackLayer(C.Structure):
+    _fields_ = [("w_offset", C.c_int64), ("w_fwd", C.c_void_p), ("w_bwd", C.c_void_p),
+                ("Cout", C.c_int32), ("Cin", C.c_int32), ("ksize", C.c_int32), ("pad_", C.c_int32)]
+
+
 class PlanOp(C.Structure):
     _fields_ = [("kind", C.c_int32), ("pad_", C.c_int32), ("conv", ConvDesc), ("bneck", BneckDesc), ("stem", StemDesc)]
 
@@ -120,6 +134,13 @@ _PROTOS = {
                                         C.c_int, C.c_float, C.c_void_p]),
     "od_sgd_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_float,
                               C.c_float, C.c_float, C.c_void_p]),
+    "od_conv2d_bwd_weight_splits": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "od_conv2d_bwd_weight_slabs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "od_wgrad_reduce_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "od_sgd_step_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                                    C.c_float, C.c_void_p]),
+    "od_pack_weights_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "od_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p]),
     "od_conv_first_bwd_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

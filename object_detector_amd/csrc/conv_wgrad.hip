@@ -10,6 +10,8 @@
 //
 // Replaces the weight-gradient half of the Keras Conv2D backward pass of the reference's (unseen) training loop
 // (SURVEY.md §2.2 K11); results are f32 (loss-scaled), consumed by od_sgd_step.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 namespace {
@@ -19,7 +21,8 @@ typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 struct WgradKP {
   const f16* x;    // [B,H,W,Cin]
   const f16* dz;   // [B,Ho,Wo,Cout]
-  float* dw;       // [Cout][Ktot] f32, dense (the layout of the f32 master weights)
+  float* dw;       // [Cout][Ktot] f32, dense (the layout of the f32 master weights); atomic adds when slabs == null
+  float* slabs;    // or: [split][Cout][Ktot] partial sums, plain stores (od_wgrad_reduce_multi adds them in a fixed order)
   const f16* zero;
   int H, W, Cin, Ho, Wo, Cout, ks, stride, pad;
   int Kstride, Ktot, M, HoWo;
@@ -30,11 +33,15 @@ constexpr int KC = 32;          // pixels per K chunk (one MFMA k step)
 constexpr int TILE = 128;       // out tile edge
 constexpr int ROWB = 256;       // LDS row bytes (128 f16)
 constexpr int OPER_BYTES = KC * ROWB;  // 8 KiB per operand per stage
+#ifndef OD_WG_NSTAGE
+#define OD_WG_NSTAGE 3
+#endif
+constexpr int NSTAGE = OD_WG_NSTAGE;       // LDS ring: chunk c+3 streams in while chunk c is multiplied (64 KiB, 2 workgroups per CU)
 
 __device__ __forceinline__ int swz_key(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }
 
 __global__ __launch_bounds__(256, 2) void od_conv_wgrad(WgradKP p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * OPER_BYTES];  // [stage][D | X]
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * 2 * OPER_BYTES];  // [stage][D | X]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
@@ -69,23 +76,41 @@ __global__ __launch_bounds__(256, 2) void od_conv_wgrad(WgradKP p) {
     dcol_ok[h] = (co0 + lchunk[h] * 8) < p.Cout;
   }
 
-  auto stage = [&](int chunk, int buf) {
+  // pixel coordinates of this lane's two tile rows for the NEXT chunk to be staged, advanced by KC per chunk (no division
+  // in the loop: Wo >= 10 here, so a 32-pixel step wraps at most a few rows)
+  int sm[2], sb[2], sho[2], swo[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    sm[h] = chunk0 * KC + prow[h];
+    const unsigned b = (unsigned)sm[h] / (unsigned)p.HoWo;
+    const unsigned pix = (unsigned)sm[h] - b * (unsigned)p.HoWo;
+    sb[h] = (int)b;
+    sho[h] = (int)(pix / (unsigned)p.Wo);
+    swo[h] = (int)(pix - (unsigned)sho[h] * (unsigned)p.Wo);
+  }
+  auto stage = [&](int buf) {  // stages are issued strictly in chunk order
     char* dbuf = smem + buf * 2 * OPER_BYTES;
     char* xbuf = dbuf + OPER_BYTES;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int q = wave + 4 * h;
-      const int m = (chunk0 + chunk) * KC + prow[h];
+      const int m = sm[h];
       const bool mok = m < p.M;
-      const unsigned b = (unsigned)m / (unsigned)p.HoWo;
-      const unsigned pix = (unsigned)m - b * (unsigned)p.HoWo;
-      const unsigned ho = pix / (unsigned)p.Wo, wo = pix - ho * (unsigned)p.Wo;
       const f16* dsrc = (mok && dcol_ok[h]) ? p.dz + ((long long)m * p.Cout + co0 + lchunk[h] * 8) : p.zero;
       glds16(dsrc, dbuf + q * 1024);
-      const int hi = (int)ho * p.stride + xtap_dy[h] - p.pad, wi = (int)wo * p.stride + xtap_dx[h] - p.pad;
+      const int hi = sho[h] * p.stride + xtap_dy[h] - p.pad, wi = swo[h] * p.stride + xtap_dx[h] - p.pad;
       const bool xok = mok && xcol_ok[h] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      const f16* xsrc = xok ? p.x + ((((long long)b * p.H + hi) * p.W + wi) * p.Cin + xci[h]) : p.zero;
+      const f16* xsrc = xok ? p.x + ((((long long)sb[h] * p.H + hi) * p.W + wi) * p.Cin + xci[h]) : p.zero;
       glds16(xsrc, xbuf + q * 1024);
+      sm[h] += KC;
+      swo[h] += KC;
+      while (swo[h] >= p.Wo) {
+        swo[h] -= p.Wo;
+        if (++sho[h] == p.Ho) {
+          sho[h] = 0;
+          ++sb[h];
+        }
+      }
     }
   };
 
@@ -107,11 +132,26 @@ __global__ __launch_bounds__(256, 2) void od_conv_wgrad(WgradKP p) {
     rkey[h] = swz_key(r);
   }
 
-  stage(0, 0);
-  __syncthreads();  // vmcnt(0): chunk 0 landed
-  for (int c = 0; c < nch; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < nch) stage(c + 1, buf ^ 1);
+  // ring: chunks are staged NSTAGE-1 ahead; a counted vmcnt retires chunk c and leaves the later ones in flight (4 DMAs per
+  // chunk per wave), one raw s_barrier per chunk (every wave's piece of chunk c landed; chunk c-1's buffer is free)
+#pragma unroll
+  for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+    if (s0 < nch) stage(s0);
+  int buf = 0, sbuf = NSTAGE - 1;  // buffer of chunk c / of the next chunk to stage
+  for (int c = 0; c < nch; ++c, buf = (buf + 1 == NSTAGE ? 0 : buf + 1)) {
+    // chunks c+1 .. c+NSTAGE-2 may stay in flight
+    if (NSTAGE >= 4 && c + 2 < nch) {
+      wait_vmcnt<8>();
+    } else if (NSTAGE >= 3 && c + 1 < nch) {
+      wait_vmcnt<4>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (c + NSTAGE - 1 < nch) {
+      stage(sbuf);
+      sbuf = sbuf + 1 == NSTAGE ? 0 : sbuf + 1;
+    }
     const char* dbuf = smem + buf * 2 * OPER_BYTES;
     const char* xbuf = dbuf + OPER_BYTES;
     f16x8 af[4], bf[4];
@@ -145,7 +185,6 @@ __global__ __launch_bounds__(256, 2) void od_conv_wgrad(WgradKP p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    __syncthreads();
   }
 
   // ---- f32 partial tile -> dW (atomic adds; 16 lanes = 64 contiguous bytes per row) ---------------------------
@@ -158,7 +197,10 @@ __global__ __launch_bounds__(256, 2) void od_conv_wgrad(WgradKP p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int co = co0 + wr * 64 + i * 16 + lq * 4 + e;
-          if (co < p.Cout) atomicAdd(p.dw + (long long)co * p.Kstride + col, acc[i][j][e]);
+          if (co < p.Cout) {
+            if (p.slabs) p.slabs[((long long)sp * p.Cout + co) * p.Kstride + col] = acc[i][j][e];
+            else atomicAdd(p.dw + (long long)co * p.Kstride + col, acc[i][j][e]);
+          }
         }
       }
     }
@@ -166,9 +208,26 @@ __global__ __launch_bounds__(256, 2) void od_conv_wgrad(WgradKP p) {
 
 }  // namespace
 
-extern "C" int od_conv2d_bwd_weight(od_ctx* ctx, const void* x, const void* dz, float* dw, int B, int H, int W, int Cin,
-                                    int Cout, int ksize, int stride, void* stream) {
-  OD_REQUIRE(ctx && x && dz && dw, "od_conv2d_bwd_weight: null argument");
+static int wgrad_split(const od_ctx* ctx, int M, int Cout, int Ktot, int* chunks_per_split) {
+  const int rtiles = od_ceil_div(Cout, TILE), ctiles = od_ceil_div(Ktot, TILE);
+  const int nchunks = od_ceil_div(M, KC);
+  const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
+  static int split_mul = -1;  // workgroups per CU the pixel split aims at (OD_WGRAD_SPLIT; every workgroup emits a full
+  if (split_mul < 0) {        // 64 KiB f32 tile, so more splits = more partial-sum traffic)
+    const char* e = getenv("OD_WGRAD_SPLIT");
+    split_mul = e ? atoi(e) : 2;  // measured on the batch-32 step: 4 -> 18.2 ms, 2 -> 17.5 ms, 1 -> 18.7 ms
+  }
+  int split = od_ceil_div(split_mul * cus, rtiles * ctiles);
+  if (split > nchunks) split = nchunks;
+  if (split < 1) split = 1;
+  const int cps = od_ceil_div(nchunks, split);
+  if (chunks_per_split) *chunks_per_split = cps;
+  return od_ceil_div(nchunks, cps);
+}
+
+static int wgrad_impl(od_ctx* ctx, const void* x, const void* dz, float* dw, float* slabs, int B, int H, int W, int Cin,
+                      int Cout, int ksize, int stride, void* stream, int* nsplit) {
+  OD_REQUIRE(ctx && x && dz && (dw || slabs), "od_conv2d_bwd_weight: null argument");
   OD_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "od_conv2d_bwd_weight: bad ksize/stride");
   OD_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0,
              "od_conv2d_bwd_weight: Cin/Cout must be multiples of 8");
@@ -176,6 +235,7 @@ extern "C" int od_conv2d_bwd_weight(od_ctx* ctx, const void* x, const void* dz, 
   p.x = (const f16*)x;
   p.dz = (const f16*)dz;
   p.dw = dw;
+  p.slabs = slabs;
   p.zero = (const f16*)ctx->zero_page;
   p.H = H;
   p.W = W;
@@ -194,14 +254,55 @@ extern "C" int od_conv2d_bwd_weight(od_ctx* ctx, const void* x, const void* dz, 
   p.HoWo = p.Ho * p.Wo;
   p.rtiles = od_ceil_div(Cout, TILE);
   p.ctiles = od_ceil_div(p.Ktot, TILE);
-  const int nchunks = od_ceil_div(p.M, KC);
-  const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
-  int split = od_ceil_div(4 * cus, p.rtiles * p.ctiles);
-  if (split > nchunks) split = nchunks;
-  if (split < 1) split = 1;
-  p.chunks_per_split = od_ceil_div(nchunks, split);
-  p.split = od_ceil_div(nchunks, p.chunks_per_split);
+  p.split = wgrad_split(ctx, p.M, Cout, p.Ktot, &p.chunks_per_split);
+  if (nsplit) *nsplit = p.split;
   hipLaunchKernelGGL(od_conv_wgrad, dim3(p.rtiles * p.ctiles * p.split), dim3(256), 0, (hipStream_t)stream, p);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
+extern "C" int od_conv2d_bwd_weight(od_ctx* ctx, const void* x, const void* dz, float* dw, int B, int H, int W, int Cin,
+                                    int Cout, int ksize, int stride, void* stream) {
+  return wgrad_impl(ctx, x, dz, dw, nullptr, B, H, W, Cin, Cout, ksize, stride, stream, nullptr);
+}
+
+extern "C" int od_conv2d_bwd_weight_splits(od_ctx* ctx, int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+  if (!ctx || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2))
+    return 0;
+  const int pad = ksize / 2;
+  const long long M = (long long)B * ((H + 2 * pad - ksize) / stride + 1) * ((W + 2 * pad - ksize) / stride + 1);
+  return wgrad_split(ctx, (int)M, Cout, ksize * ksize * Cin, nullptr);
+}
+
+extern "C" int od_conv2d_bwd_weight_slabs(od_ctx* ctx, const void* x, const void* dz, float* slabs, int B, int H, int W,
+                                          int Cin, int Cout, int ksize, int stride, void* stream) {
+  OD_REQUIRE(slabs, "od_conv2d_bwd_weight_slabs: null slabs");
+  return wgrad_impl(ctx, x, dz, nullptr, slabs, B, H, W, Cin, Cout, ksize, stride, stream, nullptr);
+}
+
+namespace {
+// grads[dw_offset + i] = sum over the layer's slabs, ascending slab index (bit-reproducible); blockIdx.y = layer
+__global__ __launch_bounds__(256) void od_wgrad_reduce_k(const od_wgrad_red* __restrict__ tbl, float* __restrict__ grads) {
+  const od_wgrad_red e = tbl[blockIdx.y];
+  float* out = grads + e.dw_offset;
+  const long long n4 = e.count >> 2;  // counts are multiples of 8 (Cin, Cout % 8 == 0)
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    f32x4 s = *(const f32x4*)(e.slabs + i * 4);
+    for (int k = 1; k < e.nslabs; ++k) {
+      const f32x4 v = *(const f32x4*)(e.slabs + (long long)k * e.count + i * 4);
+      s[0] += v[0];
+      s[1] += v[1];
+      s[2] += v[2];
+      s[3] += v[3];
+    }
+    *(f32x4*)(out + i * 4) = s;
+  }
+}
+}  // namespace
+
+extern "C" int od_wgrad_reduce_multi(od_ctx* ctx, const od_wgrad_red* table, int nlayers, float* grads, void* stream) {
+  OD_REQUIRE(ctx && table && grads && nlayers > 0 && nlayers <= 65535, "od_wgrad_reduce_multi: bad argument");
+  hipLaunchKernelGGL(od_wgrad_reduce_k, dim3(256, nlayers), dim3(256), 0, (hipStream_t)stream, table, grads);
   OD_CHECK_LAUNCH();
   return OD_OK;
 }

@@ -326,6 +326,40 @@ __global__ __launch_bounds__(256) void od_pack_w_k(const float* __restrict__ w, 
   }
 }
 
+// multi-tensor forms: blockIdx.y = tensor, blockIdx.x strides over its elements
+__global__ __launch_bounds__(256) void od_sgd_multi_k(float* __restrict__ w, float* __restrict__ m, const float* __restrict__ g,
+                                                      const od_sgd_seg* __restrict__ segs, float momentum, float inv_scale) {
+  const od_sgd_seg sg = segs[blockIdx.y];
+  float* ws = w + sg.offset;
+  float* ms = m + sg.offset;
+  const float* gs = g + sg.offset;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < sg.count; i += (long long)gridDim.x * 256) {
+    const float grad = gs[i] * inv_scale + sg.weight_decay * ws[i];
+    const float mv = momentum * ms[i] + grad;
+    ms[i] = mv;
+    ws[i] -= sg.lr * mv;
+  }
+}
+
+__global__ __launch_bounds__(256) void od_pack_multi_k(const float* __restrict__ wflat, const od_pack_layer* __restrict__ layers) {
+  const od_pack_layer L = layers[blockIdx.y];
+  const int taps = L.ksize * L.ksize;
+  const int Kpad = (taps * L.Cin + 63) / 64 * 64, Kpad_t = (taps * L.Cout + 63) / 64 * 64;
+  const float* w = wflat + L.w_offset;
+  f16* wf = (f16*)L.w_fwd;
+  f16* wt = (f16*)L.w_bwd;
+  const long long n = (long long)L.Cout * taps * L.Cin;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int ci = (int)(i % L.Cin);
+    const long long r = i / L.Cin;
+    const int tap = (int)(r % taps);
+    const int co = (int)(r / taps);
+    const f16 v = (f16)w[i];
+    wf[(long long)co * Kpad + tap * L.Cin + ci] = v;
+    if (wt) wt[(long long)ci * Kpad_t + (taps - 1 - tap) * L.Cout + co] = v;
+  }
+}
+
 // loss gradient w.r.t. pred (f32 [B,P,C], rows of one pyramid level) -> loss-scaled f16 NHWC gradient of that level's
 // prediction conv output [B, rows*C] (rows = H*W*8 priors, C = 2+NC+4 -> H*W x 8*C channels)
 __global__ __launch_bounds__(256) void od_pred_grad_level_k(const float* __restrict__ g, f16* __restrict__ dz, int B,
@@ -441,6 +475,24 @@ extern "C" int od_sgd_step(od_ctx* ctx, float* w, float* m, const float* g, long
   OD_REQUIRE(ctx && w && m && g && n > 0, "od_sgd_step: bad argument");
   hipLaunchKernelGGL(od_sgd_k, dim3(grid_for((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, w, m, g, n, lr, momentum,
                      weight_decay, inv_loss_scale);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
+extern "C" int od_sgd_step_multi(od_ctx* ctx, float* w, float* m, const float* g, const od_sgd_seg* segs, int nseg,
+                                 float momentum, float inv_loss_scale, void* stream) {
+  OD_REQUIRE(ctx && w && m && g && segs && nseg > 0 && nseg <= 65535, "od_sgd_step_multi: bad argument");
+  hipLaunchKernelGGL(od_sgd_multi_k, dim3(256, nseg), dim3(256), 0, (hipStream_t)stream, w, m, g, segs, momentum,
+                     inv_loss_scale);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
+extern "C" int od_pack_weights_multi(od_ctx* ctx, const float* w, const od_pack_layer* layers, int nlayers, void* stream) {
+  OD_REQUIRE(ctx && w && layers && nlayers > 0 && nlayers <= 65535, "od_pack_weights_multi: bad argument");
+  // 1024 x 256 threads per layer: the largest layers (4.7 M weights, transposed 2-byte scatter for the backward pack) need the
+  // parallelism; the blocks of small layers exit after one test
+  hipLaunchKernelGGL(od_pack_multi_k, dim3(1024, nlayers), dim3(256), 0, (hipStream_t)stream, w, layers);
   OD_CHECK_LAUNCH();
   return OD_OK;
 }

@@ -110,7 +110,31 @@ class Trainer:
         o, n = self.seg[(name, kind)]
         return buf[o:o + n]
 
+    def _device_table(self, structs):
+        """ctypes structs -> one device buffer (uploaded once; the multi-tensor kernels read it)"""
+        raw = b"".join(bytes(st) for st in structs)
+        return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+
     def _repack(self):
+        if getattr(self, "_pack_table", None) is None:
+            layers = []
+            for name, (_n, cin, cout, k, _s, _bn) in self.specs.items():
+                if name == "b.conv0":
+                    continue
+                L = _lib.PackLayer()
+                L.w_offset = self.seg[(name, "w")][0]
+                L.w_fwd, L.w_bwd = self.wf[name].data_ptr(), self.wb[name].data_ptr()
+                L.Cout, L.Cin, L.ksize = cout, cin, k
+                layers.append(L)
+            self._pack_table, self._pack_n = self._device_table(layers), len(layers)
+        w0 = self.view(self.params, "b.conv0", "w")
+        wf0 = self.wf["b.conv0"]
+        wf0.zero_()
+        wf0[:, :27] = w0.view(32, 27).to(torch.float16)  # 1.7 KB: plain torch copy is fine here
+        _lib.check(self.lib.od_pack_weights_multi(self.ctx.handle, self.params.data_ptr(), self._pack_table.data_ptr(),
+                                                  self._pack_n, _stream_ptr()), "od_pack_weights_multi")
+
+    def _repack_per_layer(self):
         for name, (_n, cin, cout, k, _s, _bn) in self.specs.items():
             w = self.view(self.params, name, "w")
             if name == "b.conv0":
@@ -236,10 +260,39 @@ class Trainer:
             t = self.gradbuf[key] = torch.empty_like(self.tensors[key])
         return t
 
+    def _build_wgrad_slabs(self):
+        """Slab regions of the deterministic weight-gradient path: per layer, the slabs of all its nodes (a shared layer has
+        one node per pyramid level) are contiguous so that one table entry sums them."""
+        lib, h = self.lib, self.ctx.handle
+        per_layer = {}
+        for n in self.nodes:
+            if n.first:
+                continue
+            sp = lib.od_conv2d_bwd_weight_splits(h, self.B, n.H, n.W, n.Cin, n.Cout, n.k, n.stride)
+            assert sp > 0
+            per_layer.setdefault(n.name, []).append((n, sp))
+        total = sum(sum(sp for _n, sp in lst) * lst[0][0].Cout * lst[0][0].k ** 2 * lst[0][0].Cin for lst in per_layer.values())
+        self.wgrad_slabs = torch.empty(total, dtype=torch.float32, device=self.device)
+        self._slab_ptr, entries, off = {}, [], 0
+        for name, lst in per_layer.items():
+            n0 = lst[0][0]
+            count = n0.Cout * n0.k ** 2 * n0.Cin
+            e = _lib.WgradRed()
+            e.dw_offset, e.count = self.seg[(name, "w")][0], count
+            e.slabs = self.wgrad_slabs.data_ptr() + 4 * off
+            e.nslabs = sum(sp for _n, sp in lst)
+            entries.append(e)
+            for n, sp in lst:
+                self._slab_ptr[id(n)] = self.wgrad_slabs.data_ptr() + 4 * off
+                off += sp * count
+        self._wgrad_table, self._wgrad_n = self._device_table(entries), len(entries)
+
     def backward(self):
         """grad_pred -> self.grads (f32, loss-scaled sums over this rank's batch)."""
         lib, h = self.lib, self.ctx.handle
         s = _stream_ptr()
+        if getattr(self, "_wgrad_table", None) is None:
+            self._build_wgrad_slabs()
         self.grads.zero_()
         have = set()
         for n in reversed(self.nodes):
@@ -280,8 +333,8 @@ class Trainer:
                 _lib.check(lib.od_conv_first_bwd_weight(h, x.data_ptr(), dz.data_ptr(), dw.data_ptr(), self.B, n.H, n.W,
                                                         n.Cout, 1.0 / 255.0, s), "od_conv_first_bwd_weight")
                 continue
-            _lib.check(lib.od_conv2d_bwd_weight(h, x.data_ptr(), dz.data_ptr(), dw.data_ptr(), self.B, n.H, n.W, n.Cin,
-                                                n.Cout, n.k, n.stride, s), f"wgrad {n.name}")
+            _lib.check(lib.od_conv2d_bwd_weight_slabs(h, x.data_ptr(), dz.data_ptr(), self._slab_ptr[id(n)], self.B, n.H, n.W,
+                                                      n.Cin, n.Cout, n.k, n.stride, s), f"wgrad {n.name}")
             if not n.need_dx:
                 continue
             g = self._grad(n.x)
@@ -297,6 +350,9 @@ class Trainer:
                 d.res, d.res_mode = None, _lib.OD_RES_NONE
             _lib.check(lib.od_conv2d_fwd(h, C.byref(d), s), f"dgrad {n.name}")
             have.add(n.x)
+        # conv weight gradients: every layer's per-split slabs summed in a fixed order by ONE launch (no atomics)
+        _lib.check(lib.od_wgrad_reduce_multi(h, self._wgrad_table.data_ptr(), self._wgrad_n, self.grads.data_ptr(), s),
+                   "od_wgrad_reduce_multi")
         # shared-layer BN gradients were accumulated over the three levels inside od_bn_bwd
         return self.grads
 
@@ -311,6 +367,25 @@ class Trainer:
             dp_allreduce_(self.grads)
 
     def sgd(self):
+        """One multi-tensor launch over the flat parameter buffer (per-segment LR multipliers of docs/MODEL.md:84-90 and
+        weight decay in a device table), one multi-layer re-pack launch."""
+        inv = dp_effective_scale(self.loss_scale, self.world)  # grads are averaged over ranks
+        key = (self.lr, self.weight_decay)
+        if getattr(self, "_sgd_key", None) != key:
+            segs = []
+            for (name, kind), (o, n) in self.seg.items():
+                sg = _lib.SgdSeg()
+                sg.offset, sg.count = o, n
+                sg.lr = self.lr * lr_multiplier(name)
+                sg.weight_decay = self.weight_decay if kind == "w" else 0.0
+                segs.append(sg)
+            self._sgd_table, self._sgd_n, self._sgd_key = self._device_table(segs), len(segs), key
+        _lib.check(self.lib.od_sgd_step_multi(self.ctx.handle, self.params.data_ptr(), self.mom.data_ptr(),
+                                              self.grads.data_ptr(), self._sgd_table.data_ptr(), self._sgd_n,
+                                              self.momentum, inv, _stream_ptr()), "od_sgd_step_multi")
+        self._repack()
+
+    def sgd_per_tensor(self):
         inv = dp_effective_scale(self.loss_scale, self.world)  # grads are averaged over ranks
         for (name, kind), (o, n) in self.seg.items():
             lr = self.lr * lr_multiplier(name)
@@ -318,7 +393,7 @@ class Trainer:
             _lib.check(self.lib.od_sgd_step(self.ctx.handle, self.params.data_ptr() + 4 * o, self.mom.data_ptr() + 4 * o,
                                             self.grads.data_ptr() + 4 * o, n, lr, self.momentum, wd, inv, _stream_ptr()),
                        "od_sgd_step")
-        self._repack()
+        self._repack_per_layer()
 
     def step(self, x_u8, annotations=None, y_target=None):
         """One training step.  annotations: list[ObjectsAnnotation] (encoded on the device) or y_target [B,P,C]."""
