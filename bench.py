@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--size", type=int, default=320)
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 32 @320, 16 @640)")
     ap.add_argument("--graph", action="store_true", help="replay the network as a hipGraph")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="batches in flight on separate HIP streams (1 = every step waits for the previous one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
@@ -157,11 +159,16 @@ def main():
     from object_detector_amd.detector import ObjectDetector
     size = a.size
     batch = a.batch or (32 if size <= 320 else 16)
-    od = ObjectDetector.synthetic(batch, (size, size), seed=2, device=dev, use_multi_gpu=world > 1)
+    od = ObjectDetector.synthetic(batch, (size, size), seed=2, device=dev, use_multi_gpu=world > 1,
+                                  n_inflight=1 if a.graph else a.inflight)
     rng = np.random.default_rng(1000 + rank)  # each rank its own shard of synthetic images
     x = torch.from_numpy(rng.integers(0, 256, (batch, size, size, 3), dtype=np.uint8)).to(dev)
 
     def step():
+        # one pass of the hot path over one batch; with --inflight > 1 the step is queued on the next pipeline's stream and
+        # overlaps the tail of the previous steps (every step is complete before the closing synchronize)
+        if od.n_inflight > 1:
+            return od.submit(x, conf_threshold=0.01)
         return od.predict_batch_device(x, conf_threshold=0.01, graph=a.graph)
 
     def barrier():
@@ -246,7 +253,8 @@ def main():
                                    f"top-k + NMS), batch {batch} per GPU, synthetic VOC-shaped uint8 input, "
                                    f"random-init weights",
                        "global_batch": world * batch, "input_size": size, "parallelism": f"dp{world}",
-                       "graph": bool(a.graph), "kept_boxes_rank0_img0": int(keep_count[0])},
+                       "graph": bool(a.graph), "batches_in_flight": od.n_inflight,
+                       "kept_boxes_rank0_img0": int(keep_count[0])},
             "roofline": {"bound": "mfma", "kernel": dom, "launches_per_step": g["n"],
                          "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F16_TFLOPS, 4),

@@ -37,17 +37,18 @@ def main():
     ap.add_argument("--size", type=int, default=320)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--splits", default="1,2,4")
+    ap.add_argument("--full", action="store_true", help="every stream runs the FULL batch (pipelining of whole steps)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     for S in [int(v) for v in a.splits.split(",")]:
-        b = a.batch // S
+        b = a.batch if a.full else a.batch // S
         dets = [ObjectDetector.synthetic(b, (a.size, a.size), device="cuda:0", use_multi_gpu=False) for _ in range(S)]
         g = torch.Generator(device="cpu").manual_seed(0)
         xs = [torch.randint(0, 256, (b, a.size, a.size, 3), dtype=torch.uint8, generator=g).to(dev) for _ in range(S)]
         streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
         for graph in (False, True):
             ms = bench(dets, xs, streams, a.steps, graph)
-            print(f"splits={S} sub-batch={b} graph={graph}: {ms:.3f} ms/step  {a.batch / ms * 1e3:.0f} img/s", flush=True)
+            print(f"splits={S} sub-batch={b} graph={graph}: {ms:.3f} ms/step  {b * S / ms * 1e3:.0f} img/s", flush=True)
         del dets
 
 

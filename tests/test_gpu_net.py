@@ -108,3 +108,32 @@ def test_keep_aspect_boxes_map_back(cuda):
     od = ObjectDetector.synthetic(2, (96, 96), keep_aspect=True, device=cuda)
     p = od.predict([img, img])
     assert len(p) == 2 and (p[0].bboxes >= 0).all() and (p[0].bboxes <= 1).all()
+
+
+def test_batches_in_flight_match_sequential(cuda):
+    """submit()/collect(): three different batches queued on three pipelines (own buffers, own HIP streams) give exactly the
+    kept indices of the one-at-a-time path, and predict() (which pipelines its batches) returns them in input order."""
+    from object_detector_amd.detector import ObjectDetector
+    od = ObjectDetector.synthetic(2, (64, 64), seed=4, device=cuda, use_multi_gpu=False, n_inflight=3)
+    assert od.n_inflight == 3
+    rng = np.random.default_rng(0)
+    xs = [torch.from_numpy(rng.integers(0, 256, (2, 64, 64, 3), dtype=np.uint8)).to(cuda) for _ in range(5)]
+    ref = []
+    for x in xs:
+        kf, kc = od.predict_batch_device(x, conf_threshold=0.01)
+        torch.cuda.synchronize()
+        ref.append((kf.cpu().numpy().copy(), kc.cpu().numpy().copy()))
+    tickets = [od.submit(x, 0.01) for x in xs[:3]]
+    for t, (rkf, rkc) in zip(tickets, ref[:3]):
+        kf, kc = od.collect(t)
+        assert np.array_equal(kc.cpu().numpy(), rkc) and np.array_equal(kf.cpu().numpy(), rkf)
+    # a pipeline is reused in stream order: ticket 0 again
+    t = od.submit(xs[3], 0.01)
+    kf, kc = od.collect(t)
+    assert np.array_equal(kc.cpu().numpy(), ref[3][1]) and np.array_equal(kf.cpu().numpy(), ref[3][0])
+    imgs = [x[i].cpu().numpy() for x in xs for i in range(2)]   # 10 images = 5 batches through predict()
+    preds = od.predict(imgs, conf_threshold=0.01)
+    assert len(preds) == 10
+    for b, (rkf, rkc) in enumerate(ref):
+        for i in range(2):
+            assert np.array_equal(preds[2 * b + i].flat_indices, rkf[i, :rkc[i]])
