@@ -81,7 +81,8 @@ typedef struct od_conv_desc {
   int32_t out_dtype; /* OD_DT_* */
   int64_t out_batch_stride;
   int64_t out_pix_stride;
-  int32_t tile_cfg; /* -1 = auto; otherwise index into the tile-config table (od_conv_num_tile_cfgs) */
+  int32_t tile_cfg; /* -1 = auto (fastest launch on an idle chip); -2 = auto for launches that overlap other work (batches
+                       in flight): least CU x time; otherwise index into the tile-config table (od_conv_num_tile_cfgs) */
   int32_t transposed; /* != 0: backward-data of a 3x3 stride-2 conv: x is [B,H,W,Cin] = dZ, out is [B,2H,2W,Cout];
                          w must be the flipped / channel-swapped pack written by od_pack_weights */
   int32_t splitk;     /* split-K factor for small-M layers: 0 = library decides, 1 = off; needs splitk_workspace */

@@ -412,7 +412,7 @@ const TileCfg g_cfgs[] = {
 constexpr int kNumCfgs = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
 // Tile choice from the measured table (profiles/r01/conv_cfg_sweep.txt; MI355X, batch-32 Darknet53 shapes).
-int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize, bool e8_ok) {
+int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize, bool e8_ok, bool throughput) {
   const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
   const bool spec_ok = (Cin % 64) == 0;  // wave-specialised kernels are tap-uniform only
   if (Cout <= 64) return (ksize == 3 && od_ceil_div(M, 128) >= 8 * cus) ? 1 : 3;
@@ -429,6 +429,25 @@ int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize, bool e8_ok)
     if (t128 < cus) return 13;
   }
   if (!spec_ok) return t128 >= 2L * cus ? 0 : 2;
+  if (throughput && e8_ok && ksize == 3 && Cout >= 192 && M >= 2048) {
+    // tile_cfg = -2: other launches overlap this one (batches in flight on several streams), so an under-filled grid is
+    // not wasted and the figure of merit is CU x time, not time: the 8-wave kernel (one workgroup per CU, half the
+    // L2->LDS bytes per flop) then also takes the stage-4 / stage-5 layers (profiles/r01/inflight_sweep.txt: +4.5 % img/s)
+    const int nk = od_ceil_div(ksize * ksize * Cin, 64);
+    double best = t128 >= cus ? t128 * (7.5 + 1.07 * nk) * 0.5 : t128 * (10.0 + 0.55 * nk);
+    int pick = t128 >= cus ? 13 : (Cout <= 256 ? 27 : 14);
+    for (int i = 0; i < od_conv_8ph_num_cfgs(); ++i) {
+      const int mt = 8 - i, bm = 32 * mt;
+      const long tiles = (long)od_ceil_div(M, bm) * od_ceil_div(Cout, 256);
+      if (tiles * 3 < cus) continue;  // a grid below a third of the chip gained nothing (stage 5, coarse head levels)
+      const double c = (double)tiles * (13.0 + 1.78 * nk * (0.5 + 0.0625 * mt));
+      if (c < 0.95 * best) {
+        best = c / 0.95;
+        pick = kNumCfgs + od_conv_win_num_cfgs() + 1 + i;
+      }
+    }
+    return pick;
+  }
   if (t128 >= cus) {
     if (Cout == 128) return 2;
     // 128x128 specialised kernel (2 workgroups per CU) vs the 8-wave BM x 256 kernel (1 per CU): whole rounds x
@@ -494,7 +513,7 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
   int cfg = d->tile_cfg;
   if (cfg < 0)
     cfg = pick_cfg(ctx, M, d->Cin, d->Cout, d->ksize,
-                   !tconv && (long long)d->B * d->H * d->W * d->Cin * 2 < 0x7F000000LL);
+                   !tconv && (long long)d->B * d->H * d->W * d->Cin * 2 < 0x7F000000LL, cfg == -2);
   const int cfg_pw = kNumCfgs + od_conv_win_num_cfgs(), cfg_e8 = cfg_pw + 1;
   OD_REQUIRE(cfg < cfg_e8 + od_conv_8ph_num_cfgs(), "od_conv2d_fwd: tile_cfg %d out of range", cfg);
   const bool use_pw = cfg == cfg_pw;

@@ -120,7 +120,8 @@ class ObjectDetector:
         self.num_classes, _, _ = W.infer_arch(params)
         kw = {} if prior_wh is None else {"prior_wh": prior_wh}
         self.pb = PriorBoxes(self.input_size, self.num_classes, device=self.device, **kw)
-        self.net = Net(params, self.batch_size, self.input_size, device=self.device)
+        n = int(os.environ.get("OD_INFLIGHT", 3 if n_inflight is None else n_inflight))
+        self.net = Net(params, self.batch_size, self.input_size, device=self.device, overlapped=n > 1)
         assert self.net.P == len(self.pb)
         self.post = Postprocessor(self.batch_size, self.net.P, self.num_classes, self.pb.pb_locs, device=self.device,
                                   strict_nms=self.strict_nms, loc_scale=self.pb.loc_scale)
@@ -128,10 +129,9 @@ class ObjectDetector:
         # tails, epilogue write bursts and the small post-processing kernels of one batch overlap the convolutions of the
         # next (measured +23 % images/s at batch 32 with 2-3 in flight, profiles/r01/inflight_sweep.txt).  Pipeline 0 =
         # (self.net, self.post) on the caller's stream is what predict_batch_device uses.
-        n = int(os.environ.get("OD_INFLIGHT", 3 if n_inflight is None else n_inflight))
         self._pipes = [_Pipeline(self.net, self.post, torch.cuda.Stream(device=self.device))]
         for _ in range(max(1, n) - 1):
-            net = Net(params, self.batch_size, self.input_size, device=self.device)
+            net = Net(params, self.batch_size, self.input_size, device=self.device, overlapped=True)
             post = Postprocessor(self.batch_size, net.P, self.num_classes, self.pb.pb_locs, device=self.device,
                                  strict_nms=self.strict_nms, loc_scale=self.pb.loc_scale)
             self._pipes.append(_Pipeline(net, post, torch.cuda.Stream(device=self.device)))

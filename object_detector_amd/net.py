@@ -68,7 +68,7 @@ def pad_vec(v: np.ndarray, n: int):
 
 class Net:
     def __init__(self, params, batch_size, input_size=(320, 320), device="cuda:0", backbone_act=("leaky", 0.1),
-                 head_act=("elu", 1.0), tile_cfg=None):
+                 head_act=("elu", 1.0), tile_cfg=None, overlapped=False):
         self.ctx = Context.get(device)
         self.lib = self.ctx.lib
         self.device = torch.device(device)
@@ -81,6 +81,7 @@ class Net:
         self.level_hw = [(self.H // s, self.W // s) for s in (8, 16, 32)]
         self.P = sum(h * w for h, w in self.level_hw) * W.NUM_PRIORS
         self.tile_cfg = dict(tile_cfg or {})
+        self.auto_cfg = -2 if overlapped else -1  # od_conv_desc.tile_cfg: -2 = this plan runs beside other batches in flight
         for item in filter(None, os.environ.get("OD_TILE_CFG", "").split(",")):  # tuning: "b.s3=24,n.lat=25" (name prefixes)
             pat, cfg = item.split("=")
             self.tile_cfg[pat] = int(cfg)
@@ -147,7 +148,7 @@ class Net:
         d.res_mode = res_mode
         d.out_dtype = _lib.OD_DT_F32 if out_f32 else _lib.OD_DT_F16
         d.out_batch_stride, d.out_pix_stride = obs, ops
-        d.tile_cfg = self.tile_cfg.get(name, -1)
+        d.tile_cfg = self.tile_cfg.get(name, self.auto_cfg)
         for pat, cfg in self.tile_cfg.items():  # patterns "prefix*suffix", e.g. "b.s3*a" = the 1x1 convs of stage 3
             pre, star, suf = pat.partition("*")
             if star and name.startswith(pre) and name.endswith(suf):
