@@ -160,7 +160,7 @@ def main():
     size = a.size
     batch = a.batch or (32 if size <= 320 else 16)
     od = ObjectDetector.synthetic(batch, (size, size), seed=2, device=dev, use_multi_gpu=world > 1,
-                                  n_inflight=1 if a.graph else a.inflight)
+                                  n_inflight=a.inflight)
     rng = np.random.default_rng(1000 + rank)  # each rank its own shard of synthetic images
     x = torch.from_numpy(rng.integers(0, 256, (batch, size, size, 3), dtype=np.uint8)).to(dev)
 
@@ -168,7 +168,7 @@ def main():
         # one pass of the hot path over one batch; with --inflight > 1 the step is queued on the next pipeline's stream and
         # overlaps the tail of the previous steps (every step is complete before the closing synchronize)
         if od.n_inflight > 1:
-            return od.submit(x, conf_threshold=0.01)
+            return od.submit(x, conf_threshold=0.01, graph=a.graph)
         return od.predict_batch_device(x, conf_threshold=0.01, graph=a.graph)
 
     def barrier():

@@ -172,7 +172,7 @@ class ObjectDetector:
     def n_inflight(self):
         return len(self._pipes)
 
-    def submit(self, x_u8: torch.Tensor, conf_threshold=DEFAULT_CONF_THRESHOLD) -> int:
+    def submit(self, x_u8: torch.Tensor, conf_threshold=DEFAULT_CONF_THRESHOLD, graph=False) -> int:
         """Queue one batch on the next pipeline's stream and return its ticket.  Never blocks the host: a pipeline's new
         batch is stream-ordered behind its previous one (whose results it overwrites -- collect() them first)."""
         i = self._next
@@ -180,7 +180,7 @@ class ObjectDetector:
         p = self._pipes[i]
         p.stream.wait_stream(torch.cuda.current_stream(self.device))  # x_u8 was produced on the caller's stream
         with torch.cuda.stream(p.stream):
-            pred = p.net.forward(x_u8)
+            pred = p.net.forward(x_u8, graph=graph)
             p.post.run(pred, conf_threshold)
             p.done.record()
         x_u8.record_stream(p.stream)
