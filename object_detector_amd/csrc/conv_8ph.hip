@@ -54,6 +54,14 @@ constexpr unsigned E_OOB = 0x80000000u;  // buffer offset beyond any tensor this
 template <int MT>
 static __device__ __forceinline__ void e8_epilogue_direct(const ConvKP& p, f32x4 (&acc)[MT][4], int m0w, int n0w, int l15,
                                                           int lq) {
+  // pixel decomposition once per m-fragment (shared by both fragment pairs)
+  unsigned pb[MT], ppix[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0w + i * 16 + l15;
+    pb[i] = (unsigned)m / (unsigned)p.HoWo;
+    ppix[i] = (unsigned)m - pb[i] * (unsigned)p.HoWo;
+  }
 #pragma unroll
   for (int pr = 0; pr < 2; ++pr) {
     const int n = n0w + (2 * pr + (lq & 1)) * 16 + (lq >> 1) * 8;  // this lane's 8 channels
@@ -70,23 +78,28 @@ static __device__ __forceinline__ void e8_epilogue_direct(const ConvKP& p, f32x4
         bi[4 + e] = b1[e];
       }
     }
+    // all residual rows of this pair are requested before the first one is used (MT loads in flight per lane)
+    f16x8 rv[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int m = m0w + i * 16 + l15;
-      const bool ok = nok && m < p.M;
-      const unsigned b = (unsigned)m / (unsigned)p.HoWo;
-      const unsigned pix = (unsigned)m - b * (unsigned)p.HoWo;
       f16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (ok && p.res_mode != OD_RES_NONE) {
+      if (nok && m < p.M && p.res_mode != OD_RES_NONE) {
         long long roff;
         if (p.res_mode == OD_RES_SAME) {
           roff = (long long)m * p.Cout + n;
         } else {
-          const unsigned ho = pix / (unsigned)p.Wo, wo = pix - ho * (unsigned)p.Wo;
-          roff = ((long long)(b * (unsigned)(p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout + n;
+          const unsigned ho = ppix[i] / (unsigned)p.Wo, wo = ppix[i] - ho * (unsigned)p.Wo;
+          roff = ((long long)(pb[i] * (unsigned)(p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout + n;
         }
         r = *(const f16x8*)(p.res + roff);
       }
+      rv[i] = r;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0w + i * 16 + l15;
+      const bool ok = nok && m < p.M;
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -106,10 +119,10 @@ static __device__ __forceinline__ void e8_epilogue_direct(const ConvKP& p, f32x4
       }
       if (p.res_mode != OD_RES_NONE) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+        for (int e = 0; e < 8; ++e) v[e] += (float)rv[i][e];
       }
       if (ok) {
-        const long long ooff = (long long)b * p.obs + (long long)pix * p.ops + n;
+        const long long ooff = (long long)pb[i] * p.obs + (long long)ppix[i] * p.ops + n;
         if (p.out_f32) {
           float* o = (float*)p.out + ooff;
           *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
