@@ -12,6 +12,7 @@ only gradients are exchanged.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -100,7 +101,13 @@ class Trainer:
         self.losses = torch.zeros(4, dtype=torch.float32, device=dev)
         self.loss_ws = torch.empty(self.lib.od_loss_workspace_bytes(self.B, self.P), dtype=torch.uint8, device=dev)
         mx = max(self.B * (n.H // n.stride) * (n.W // n.stride) * n.Cout for n in self.nodes)
-        self.dz = torch.empty(mx, dtype=torch.float16, device=dev)  # scratch: dz of the node being processed
+        # dz of the node being processed: three rotating buffers, because the weight gradient of node k runs on a second
+        # stream while the main stream already computes node k-1's dz (backward()); OD_TRAIN_WSTREAM=0 -> one buffer, one stream
+        self.use_wstream = os.environ.get("OD_TRAIN_WSTREAM", "1") != "0"
+        self.dzs = [torch.empty(mx, dtype=torch.float16, device=dev) for _ in range(3 if self.use_wstream else 1)]
+        self.dz = self.dzs[0]
+        self.wstream = torch.cuda.Stream(device=dev) if self.use_wstream else None
+        self._wg_done = [None] * len(self.dzs)
         mxc = max(self.lib.od_bn_workspace_bytes(self.B * (n.H // n.stride) * (n.W // n.stride), n.Cout) + 2 * n.Cout * 4
                   for n in self.nodes)
         self.bn_ws = torch.empty(mxc, dtype=torch.uint8, device=dev)
@@ -295,10 +302,14 @@ class Trainer:
             self._build_wgrad_slabs()
         self.grads.zero_()
         have = set()
-        for n in reversed(self.nodes):
+        main = torch.cuda.current_stream(self.device)
+        for k, n in enumerate(reversed(self.nodes)):
             Ho, Wo = n.H // n.stride, n.W // n.stride
             M = self.B * Ho * Wo
-            dz = self.dz[:M * n.Cout]
+            slot = k % len(self.dzs)
+            if self._wg_done[slot] is not None:
+                main.wait_event(self._wg_done[slot])  # the weight gradient that read this buffer three nodes ago
+            dz = self.dzs[slot][:M * n.Cout]
             wsb = lib.od_bn_workspace_bytes(M, n.Cout) + 2 * n.Cout * 4
             if n.pred_off is not None:
                 _lib.check(lib.od_pred_grad_to_level(h, self.grad_pred.data_ptr(), dz.data_ptr(), self.B, self.P, self.C,
@@ -329,13 +340,24 @@ class Trainer:
                                          self.bn_ws.data_ptr(), wsb, s), f"od_bn_bwd {n.name}")
             dw = self.view(self.grads, n.name, "w")
             x = self.tensors[n.x]
+            # weight gradient: needs only dz and the saved input -> second stream, beside the dz -> dx -> ... chain
+            ws = s
+            if self.wstream is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self.wstream.wait_event(ev)
+                ws = C.c_void_p(self.wstream.cuda_stream)
             if n.first:
                 _lib.check(lib.od_conv_first_bwd_weight(h, x.data_ptr(), dz.data_ptr(), dw.data_ptr(), self.B, n.H, n.W,
-                                                        n.Cout, 1.0 / 255.0, s), "od_conv_first_bwd_weight")
-                continue
-            _lib.check(lib.od_conv2d_bwd_weight_slabs(h, x.data_ptr(), dz.data_ptr(), self._slab_ptr[id(n)], self.B, n.H, n.W,
-                                                      n.Cin, n.Cout, n.k, n.stride, s), f"wgrad {n.name}")
-            if not n.need_dx:
+                                                        n.Cout, 1.0 / 255.0, ws), "od_conv_first_bwd_weight")
+            else:
+                _lib.check(lib.od_conv2d_bwd_weight_slabs(h, x.data_ptr(), dz.data_ptr(), self._slab_ptr[id(n)], self.B, n.H,
+                                                          n.W, n.Cin, n.Cout, n.k, n.stride, ws), f"wgrad {n.name}")
+            if self.wstream is not None:
+                done = torch.cuda.Event()
+                done.record(self.wstream)
+                self._wg_done[slot] = done
+            if n.first or not n.need_dx:
                 continue
             g = self._grad(n.x)
             d = _lib.ConvDesc()
@@ -350,6 +372,9 @@ class Trainer:
                 d.res, d.res_mode = None, _lib.OD_RES_NONE
             _lib.check(lib.od_conv2d_fwd(h, C.byref(d), s), f"dgrad {n.name}")
             have.add(n.x)
+        if self.wstream is not None:
+            main.wait_stream(self.wstream)
+            self._wg_done = [None] * len(self.dzs)
         # conv weight gradients: every layer's per-split slabs summed in a fixed order by ONE launch (no atomics)
         _lib.check(lib.od_wgrad_reduce_multi(h, self._wgrad_table.data_ptr(), self._wgrad_n, self.grads.data_ptr(), s),
                    "od_wgrad_reduce_multi")
