@@ -675,7 +675,10 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
     attr_done[attr_slot][variant] = true;
   }
   void* args[] = {&p};
-  OD_CHECK_HIP(hipLaunchKernel(fn, dim3(p.mtiles * p.ntiles * p.splitk), dim3(tc.threads), args, tc.lds, stream));
+  // the 8-wave kernel's epilogue needs no LDS unless it writes split-K slabs: ask only for the two K-tile buffers then
+  // (128 KiB), which leaves room on the CU for a small workgroup of another stream
+  const size_t launch_lds = (use_e8 && p.splitk <= 1 && tc.lds > (size_t)128 * 1024) ? (size_t)128 * 1024 : tc.lds;
+  OD_CHECK_HIP(hipLaunchKernel(fn, dim3(p.mtiles * p.ntiles * p.splitk), dim3(tc.threads), args, launch_lds, stream));
   if (p.splitk > 1) {
     const long long nvec = (long long)p.M * (p.Cout / 8);
     long long fb = (nvec + 255) / 256;
