@@ -131,7 +131,8 @@ class ObjectDetector:
         # (self.net, self.post) on the caller's stream is what predict_batch_device uses.
         self._pipes = [_Pipeline(self.net, self.post, torch.cuda.Stream(device=self.device))]
         for _ in range(max(1, n) - 1):
-            net = Net(params, self.batch_size, self.input_size, device=self.device, overlapped=True)
+            net = Net(params, self.batch_size, self.input_size, device=self.device, overlapped=True,
+                      share_weights_with=self.net)
             post = Postprocessor(self.batch_size, net.P, self.num_classes, self.pb.pb_locs, device=self.device,
                                  strict_nms=self.strict_nms, loc_scale=self.pb.loc_scale)
             self._pipes.append(_Pipeline(net, post, torch.cuda.Stream(device=self.device)))

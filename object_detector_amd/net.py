@@ -68,7 +68,7 @@ def pad_vec(v: np.ndarray, n: int):
 
 class Net:
     def __init__(self, params, batch_size, input_size=(320, 320), device="cuda:0", backbone_act=("leaky", 0.1),
-                 head_act=("elu", 1.0), tile_cfg=None, overlapped=False):
+                 head_act=("elu", 1.0), tile_cfg=None, overlapped=False, share_weights_with=None):
         self.ctx = Context.get(device)
         self.lib = self.ctx.lib
         self.device = torch.device(device)
@@ -91,7 +91,10 @@ class Net:
         self._splitk_descs = []
         self._keep = []  # device tensors referenced by raw pointers in the plan
         self._dev = {}
-        for name, cin, cout, k, _s, _bn in W.layer_specs(self.num_classes, self.neck_ch, self.tower):
+        if share_weights_with is not None:  # another pipeline of the same detector: the packed weights are read-only
+            self._dev = share_weights_with._dev
+        for name, cin, cout, k, _s, _bn in ([] if share_weights_with is not None else
+                                            W.layer_specs(self.num_classes, self.neck_ch, self.tower)):
             w = params[name + ".w"]
             assert w.shape == (cout, k, k, cin), (name, w.shape)
             scale, bias = W.fold_bn(params, name)
@@ -192,7 +195,8 @@ class Net:
 
     def _build(self, bact, hact):
         B, H, Wd = self.B, self.H, self.W
-        fuse_stem = self.fuse_blocks and self.lib.od_stem_supported(H, Wd)
+        fuse_stem = (self.fuse_blocks and os.environ.get("OD_FUSE_STEM", "1") != "0"
+                     and self.lib.od_stem_supported(H, Wd))
         if fuse_stem:
             # first two layers in one launch (od_stem_fwd): uint8 in, f16 [B,H/2,W/2,64] out
             w0, sc0, bi0 = self._dev["b.conv0"]
@@ -235,7 +239,8 @@ class Net:
             else:
                 x, h, w = self._conv(f"b.down{si}", x, h, w, cin, ch, 3, 2, bact)
             for r in range(n):
-                if self.fuse_blocks and self.lib.od_bottleneck_supported(h, w, ch):
+                if (self.fuse_blocks and os.environ.get(f"OD_FUSE_BNECK{ch}", "1") != "0"
+                        and self.lib.od_bottleneck_supported(h, w, ch)):
                     x = self._bneck(f"b.s{si}.{r}", x, h, w, ch, bact)
                     continue
                 t, _, _ = self._conv(f"b.s{si}.{r}.a", x, h, w, ch, ch // 2, 1, 1, bact)
