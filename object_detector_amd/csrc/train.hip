@@ -16,6 +16,7 @@
 
 namespace {
 
+constexpr int ROW_UNROLL = 4;      // rows in flight per thread in the row-walking kernels
 constexpr int RED_ROWS_MAX = 8192;  // rows per workgroup in the channel reductions (upper bound)
 
 // rows per workgroup: enough workgroups to fill the chip (>= ~2048), a multiple of the row lanes of one workgroup
@@ -25,6 +26,19 @@ static inline int rows_per_wg(long long M, int C) {
   long long r = (M + 1023) / 1024;  // <= ~1024 partial rows for the final pass
   r = (r + lanes - 1) / lanes * lanes;
   if (r < lanes) r = lanes;
+  if (r > RED_ROWS_MAX) r = RED_ROWS_MAX;
+  return (int)r;
+}
+
+// the channel reductions write one partial row per workgroup and od_chan_final walks those rows: at least 32 KiB of
+// tensor per workgroup, so that a small layer does not produce as many bytes of partials as it has data
+static inline int rows_per_wg_reduce(long long M, int C) {
+  const int G = C >> 3;
+  const int lanes = 256 / (G < 256 ? G : 256);
+  long long r = (M + 1023) / 1024;
+  const long long rmin = (32768 + 2 * C - 1) / (2 * C);
+  if (r < rmin) r = rmin;
+  r = (r + lanes - 1) / lanes * lanes;
   if (r > RED_ROWS_MAX) r = RED_ROWS_MAX;
   return (int)r;
 }
@@ -71,39 +85,68 @@ __global__ __launch_bounds__(256) void od_chan_reduce(const f16* __restrict__ z,
           rs[e] = rstd[g * 8 + e];
         }
       }
-      for (long long r = r0 + rl; r < r1; r += lanes) {
-        const f16x8 zv = *(const f16x8*)(z + r * C + g * 8);
-        if (MODE == 0) {
+      // ROW_UNROLL independent 16-B loads per tensor in flight per thread (one load per trip left the kernel at ~1.5 TB/s)
+      for (long long r = r0 + rl; r < r1; r += (long long)ROW_UNROLL * lanes) {
+        f16x8 zv[ROW_UNROLL], dv[ROW_UNROLL];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float v = (float)zv[e];
-            s0[e] += v;
-            s1[e] += v * v;
+        for (int u = 0; u < ROW_UNROLL; ++u) {
+          const long long rr = r + (long long)u * lanes;
+          if (rr < r1) {
+            zv[u] = *(const f16x8*)(z + rr * C + g * 8);
+            if (MODE == 1) dv[u] = *(const f16x8*)(dy + rr * C + g * 8);
           }
-        } else {
-          const f16x8 dv = *(const f16x8*)(dy + r * C + g * 8);
+        }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float zf = (float)zv[e];
-            const float da = (float)dv[e] * act_grad(zf * sc[e] + sh[e], act, alpha);
-            s0[e] += da;
-            s1[e] += da * ((zf - mu[e]) * rs[e]);
+        for (int u = 0; u < ROW_UNROLL; ++u) {
+          if (r + (long long)u * lanes >= r1) break;
+          if (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float v = (float)zv[u][e];
+              s0[e] += v;
+              s1[e] += v * v;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float zf = (float)zv[u][e];
+              const float da = (float)dv[u][e] * act_grad(zf * sc[e] + sh[e], act, alpha);
+              s0[e] += da;
+              s1[e] += da * ((zf - mu[e]) * rs[e]);
+            }
           }
         }
       }
     }
-    float* r0p = red + tid * 8;
-    float* r1p = red + 256 * 8 + tid * 8;
+    // fixed-order sum over the row lanes of each group: butterfly inside the wave when the G groups tile a wave
+    // (power-of-two G < 64), then over the remaining holders (waves / row lanes) through LDS
+    int hidx = rl, nh = lanes;
+    bool holder = g < G && rl < lanes;
+    if (lanes > 1 && G < 64 && (G & (G - 1)) == 0) {
+      for (int off = G; off < 64; off <<= 1) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      r0p[e] = s0[e];
-      r1p[e] = s1[e];
+        for (int e = 0; e < 8; ++e) {
+          s0[e] += __shfl_xor(s0[e], off, 64);
+          s1[e] += __shfl_xor(s1[e], off, 64);
+        }
+      }
+      hidx = tid >> 6;
+      nh = 4;
+      holder = (tid & 63) < G;
+    }
+    if (holder) {
+      float* r0p = red + (hidx * G + (g - g0)) * 8;
+      float* r1p = r0p + 256 * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        r0p[e] = s0[e];
+        r1p[e] = s1[e];
+      }
     }
     __syncthreads();
-    // fixed-order sum over the row lanes of each group
-    if (g < G && rl == 0) {
-      for (int l = 1; l < lanes; ++l) {
-        const float* a = red + (l * G + (tid % G)) * 8;
+    if (holder && hidx == 0) {
+      for (int l = 1; l < nh; ++l) {
+        const float* a = red + (l * G + (g - g0)) * 8;
         const float* b = a + 256 * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -136,9 +179,19 @@ __global__ __launch_bounds__(256) void od_chan_final(const float* __restrict__ p
   const int c = blockIdx.x * 8 + cl;
   float a = 0.f, b = 0.f;
   if (c < C) {
-    for (int i = ln; i < nblocks; i += 32) {
-      a += partials[(long long)i * 2 * C + c];
-      b += partials[(long long)i * 2 * C + C + c];
+    for (int i = ln; i < nblocks; i += 128) {  // 4 independent loads per sum in flight (was one: ~10 us of latency chain)
+      float av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ii = i + 32 * u;
+        av[u] = ii < nblocks ? partials[(long long)ii * 2 * C + c] : 0.f;
+        bv[u] = ii < nblocks ? partials[(long long)ii * 2 * C + C + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a += av[u];
+        b += bv[u];
+      }
     }
   }
   red[0][ln][cl] = a;
@@ -190,29 +243,42 @@ __global__ __launch_bounds__(256) void od_scale_act_k(const f16* __restrict__ z,
     sh[e] = shift[g * 8 + e];
   }
   const long long r0 = (long long)blockIdx.x * rows_wg, r1 = min(r0 + rows_wg, M);
-  for (long long r = r0 + rl; r < r1; r += lanes) {
-    const f16x8 zv = *(const f16x8*)(z + r * C + g * 8);
-    float v[8];
+  for (long long r = r0 + rl; r < r1; r += (long long)ROW_UNROLL * lanes) {
+    f16x8 zv[ROW_UNROLL], rv[ROW_UNROLL];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = act_fwd((float)zv[e] * sc[e] + sh[e], act, alpha);
-    if (res) {
-      long long rr = r;
-      if (res_up2) {
-        long long pix = r;
-        const int x = (int)(pix % W);
-        pix /= W;
-        const int yy = (int)(pix % H);
-        const long long b = pix / H;
-        rr = (b * (H >> 1) + (yy >> 1)) * (W >> 1) + (x >> 1);
+    for (int u = 0; u < ROW_UNROLL; ++u) {
+      const long long ru = r + (long long)u * lanes;
+      if (ru >= r1) break;
+      zv[u] = *(const f16x8*)(z + ru * C + g * 8);
+      if (res) {
+        long long rr = ru;
+        if (res_up2) {
+          long long pix = ru;
+          const int x = (int)(pix % W);
+          pix /= W;
+          const int yy = (int)(pix % H);
+          const long long b = pix / H;
+          rr = (b * (H >> 1) + (yy >> 1)) * (W >> 1) + (x >> 1);
+        }
+        rv[u] = *(const f16x8*)(res + rr * C + g * 8);
       }
-      const f16x8 rv = *(const f16x8*)(res + rr * C + g * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
     }
-    f16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
-    *(f16x8*)(y + r * C + g * 8) = o;
+    for (int u = 0; u < ROW_UNROLL; ++u) {
+      const long long ru = r + (long long)u * lanes;
+      if (ru >= r1) break;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = act_fwd((float)zv[u][e] * sc[e] + sh[e], act, alpha);
+      if (res) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)rv[u][e];
+      }
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+      *(f16x8*)(y + ru * C + g * 8) = o;
+    }
   }
 }
 
@@ -231,27 +297,40 @@ __global__ __launch_bounds__(256) void od_bn_bwd_apply_k(const f16* __restrict__
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int c = g * 8 + e;
+    // all six pointers are valid for bn == 0 too (the host passes stand-ins): unconditional loads, ONE wait --
+    // per-element `bn ? p[c] : 0` compiled to 48 serialised load round trips (a 20 us floor per launch)
     sc[e] = scale[c];
     sh[e] = shift[c];
-    mu[e] = bn ? mean[c] : 0.f;
-    rs[e] = bn ? rstd[c] : 0.f;
-    k1[e] = bn ? sum_da[c] * invM : 0.f;
-    k2[e] = bn ? sum_dax[c] * invM : 0.f;
+    mu[e] = mean[c];
+    rs[e] = rstd[c];
+    k1[e] = sum_da[c] * invM;
+    k2[e] = sum_dax[c] * invM;
   }
   const long long r0 = (long long)blockIdx.x * rows_wg, r1 = min(r0 + rows_wg, M);
-  for (long long r = r0 + rl; r < r1; r += lanes) {
-    const f16x8 zv = *(const f16x8*)(z + r * C + g * 8);
-    const f16x8 dv = *(const f16x8*)(dy + r * C + g * 8);
-    f16x8 o;
+  for (long long r = r0 + rl; r < r1; r += (long long)ROW_UNROLL * lanes) {
+    f16x8 zv[ROW_UNROLL], dv[ROW_UNROLL];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float zf = (float)zv[e];
-      const float da = (float)dv[e] * act_grad(zf * sc[e] + sh[e], act, alpha);
-      float rr = da;
-      if (bn) rr = sc[e] * (da - k1[e] - ((zf - mu[e]) * rs[e]) * k2[e]);  // scale = gamma*rstd
-      o[e] = (f16)rr;
+    for (int u = 0; u < ROW_UNROLL; ++u) {
+      const long long ru = r + (long long)u * lanes;
+      if (ru >= r1) break;
+      zv[u] = *(const f16x8*)(z + ru * C + g * 8);
+      dv[u] = *(const f16x8*)(dy + ru * C + g * 8);
     }
-    *(f16x8*)(dz + r * C + g * 8) = o;
+#pragma unroll
+    for (int u = 0; u < ROW_UNROLL; ++u) {
+      const long long ru = r + (long long)u * lanes;
+      if (ru >= r1) break;
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float zf = (float)zv[u][e];
+        const float da = (float)dv[u][e] * act_grad(zf * sc[e] + sh[e], act, alpha);
+        float rr = da;
+        if (bn) rr = sc[e] * (da - k1[e] - ((zf - mu[e]) * rs[e]) * k2[e]);  // scale = gamma*rstd
+        o[e] = (f16)rr;
+      }
+      *(f16x8*)(dz + ru * C + g * 8) = o;
+    }
   }
 }
 
@@ -381,7 +460,7 @@ unsigned grid_for(long long nvec) {
 
 extern "C" size_t od_bn_workspace_bytes(long long M, int C) {
   if (M <= 0 || C <= 0 || C % 8) return 0;
-  const int rw = rows_per_wg(M, C);
+  const int rw = rows_per_wg_reduce(M, C);
   return (size_t)((M + rw - 1) / rw) * 2 * C * sizeof(float);
 }
 
@@ -390,7 +469,7 @@ extern "C" int od_bn_stats(od_ctx* ctx, const void* z, long long M, int C, const
                            float* run_var, float momentum, void* workspace, size_t workspace_bytes, void* stream) {
   OD_REQUIRE(ctx && z && gamma && beta && mean && rstd && scale && shift && workspace, "od_bn_stats: null argument");
   OD_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "od_bn_stats: C must be a multiple of 8, <= 2048");
-  const int rw = rows_per_wg(M, C);
+  const int rw = rows_per_wg_reduce(M, C);
   const int nblocks = (int)((M + rw - 1) / rw);
   if (workspace_bytes < od_bn_workspace_bytes(M, C)) {
     od_set_error("od_bn_stats: workspace too small");
@@ -428,7 +507,7 @@ extern "C" int od_bn_bwd(od_ctx* ctx, const void* z, const void* dy, const float
   OD_REQUIRE(ctx && z && dy && scale && shift && dz && dgamma && dbeta && workspace, "od_bn_bwd: null argument");
   OD_REQUIRE(!bn || (mean && rstd), "od_bn_bwd: bn needs mean/rstd");
   OD_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "od_bn_bwd: C must be a multiple of 8, <= 2048");
-  const int rw = rows_per_wg(M, C);
+  const int rw = rows_per_wg_reduce(M, C), rw_apply = rows_per_wg(M, C);
   const int nblocks = (int)((M + rw - 1) / rw);
   const size_t need = od_bn_workspace_bytes(M, C) + 2 * (size_t)C * sizeof(float);
   if (workspace_bytes < need) {
@@ -446,9 +525,9 @@ extern "C" int od_bn_bwd(od_ctx* ctx, const void* z, const void* dy, const float
                      (const float*)nullptr, (const float*)nullptr, dgamma, dbeta, sums, sums + C, (float*)nullptr,
                      (float*)nullptr, 0.f);
   OD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(od_bn_bwd_apply_k, dim3(nblocks), dim3(256), 0, s, (const f16*)z, (const f16*)dy, scale, shift,
-                     bn ? mean : shift, bn ? rstd : scale, sums, sums + C, (f16*)dz, M, C, 1.f / (float)M, act, alpha, bn,
-                     rw);
+  hipLaunchKernelGGL(od_bn_bwd_apply_k, dim3((unsigned)((M + rw_apply - 1) / rw_apply)), dim3(256), 0, s, (const f16*)z,
+                     (const f16*)dy, scale, shift, bn ? mean : shift, bn ? rstd : scale, sums, sums + C, (f16*)dz, M, C,
+                     1.f / (float)M, act, alpha, bn, rw_apply);
   OD_CHECK_LAUNCH();
   return OD_OK;
 }
