@@ -61,6 +61,17 @@ static __device__ __forceinline__ void wait_vmcnt() {
 }
 
 
+// transposed mode: GEMM row m' -> linear output pixel index (b*HoWo + y*Wo + x).  Rows are ordered parity class by
+// parity class: m' = cls * M/4 + (b, i, j) over the SOURCE grid [Hs, Ws], pixel (y, x) = (2i + (cls >> 1), 2j + (cls & 1)).
+static __device__ __forceinline__ unsigned od_tconv_pixel(const ConvKP& p, unsigned m) {
+  const unsigned Mq = (unsigned)p.M >> 2;
+  const unsigned cls = m / Mq, idx = m - cls * Mq;
+  const unsigned HsWs = (unsigned)(p.Hs * p.Ws);
+  const unsigned b = idx / HsWs, r = idx - b * HsWs;
+  const unsigned i = r / (unsigned)p.Ws, j = r - i * (unsigned)p.Ws;
+  return b * (unsigned)p.HoWo + (2u * i + (cls >> 1)) * (unsigned)p.Wo + 2u * j + (cls & 1u);
+}
+
 // ---- epilogue shared by every conv kernel: accumulators -> LDS staging (one wave-row of the tile at a time) ->
 //      scale/bias/act (+ residual) in f32 on full NHWC lines, ONE rounding to f16, 16-B stores.
 //      acc[i][j][e] holds pixel (wave-row base + i*16 + l15), channel (wn*WTN + j*16 + lq*4 + e).
@@ -94,9 +105,10 @@ static __device__ __forceinline__ void conv_epilogue(const ConvKP& p, char* smem
     for (int wr = 0; wr < WM; ++wr)
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
-        const int m = m0 + wr * WTM + ps * RPP + tid / CH;
+        int m = m0 + wr * WTM + ps * RPP + tid / CH;
         f16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
         if (m < p.M && n < p.Cout) {
+          if (p.tconv) m = (int)od_tconv_pixel(p, (unsigned)m);
           long long roff;
           if (p.res_mode == OD_RES_SAME) {
             roff = (long long)m * p.Cout + n;
@@ -143,8 +155,9 @@ static __device__ __forceinline__ void conv_epilogue(const ConvKP& p, char* smem
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int row = ps * RPP + tid / CH;
-      const int m = m0 + wr * WTM + row;
+      int m = m0 + wr * WTM + row;
       if (m < p.M && n < p.Cout) {
+        if (p.tconv) m = (int)od_tconv_pixel(p, (unsigned)m);
         const f32x4 v0 = *(const f32x4*)(stg + row * SLD + c8);
         const f32x4 v1 = *(const f32x4*)(stg + row * SLD + c8 + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};

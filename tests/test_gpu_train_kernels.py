@@ -69,7 +69,9 @@ CONV_CASES = [  # B, H, W, Cin, Cout, k, stride
     (3, 10, 10, 128, 64, 1, 1),
     (2, 16, 16, 32, 64, 3, 1),     # Cin=32: column tile spans 4 taps in the weight gradient
     (2, 8, 8, 256, 208, 3, 1),     # ragged Cout (208)
-    (1, 20, 20, 128, 256, 3, 2),
+    (1, 20, 20, 128, 256, 3, 2),   # stride 2: backward-data rows grouped by parity class, 100 rows per class (tiles straddle)
+    (2, 32, 32, 64, 128, 3, 2),    # stride 2: whole tiles per parity class (taps skipped per tile)
+    (1, 12, 28, 32, 64, 3, 2),     # stride 2, 32 gradient channels out, non-square
     (2, 6, 10, 1024, 512, 1, 1),
 ]
 
