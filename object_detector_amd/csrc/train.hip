@@ -420,22 +420,69 @@ __global__ __launch_bounds__(256) void od_sgd_multi_k(float* __restrict__ w, flo
   }
 }
 
+// One 64 (Cout) x 64 (Cin) tile of one tap per trip: coalesced f32 reads, forward-layout rows written straight from the
+// registers (8-B stores), the backward-data layout (in/out channels swapped) through an LDS transpose as 16-B stores of
+// 8 consecutive output channels -- the per-element form scattered 40 M two-byte writes (580 us per step).
 __global__ __launch_bounds__(256) void od_pack_multi_k(const float* __restrict__ wflat, const od_pack_layer* __restrict__ layers) {
+  __shared__ f16 tile[64][68];  // [co][ci]
   const od_pack_layer L = layers[blockIdx.y];
   const int taps = L.ksize * L.ksize;
   const int Kpad = (taps * L.Cin + 63) / 64 * 64, Kpad_t = (taps * L.Cout + 63) / 64 * 64;
   const float* w = wflat + L.w_offset;
   f16* wf = (f16*)L.w_fwd;
   f16* wt = (f16*)L.w_bwd;
-  const long long n = (long long)L.Cout * taps * L.Cin;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const int ci = (int)(i % L.Cin);
-    const long long r = i / L.Cin;
-    const int tap = (int)(r % taps);
-    const int co = (int)(r / taps);
-    const f16 v = (f16)w[i];
-    wf[(long long)co * Kpad + tap * L.Cin + ci] = v;
-    if (wt) wt[(long long)ci * Kpad_t + (taps - 1 - tap) * L.Cout + co] = v;
+  const int cob = (L.Cout + 63) >> 6, cib = (L.Cin + 63) >> 6;
+  const int ntiles = taps * cob * cib;
+  const int tid = threadIdx.x;
+  const bool vec = ((L.w_offset | L.Cin) & 3) == 0;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int ib = t % cib;
+    const int r = t / cib;
+    const int ob = r % cob, tap = r / cob;
+    const int co0 = ob * 64, ci0 = ib * 64;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = (tid >> 4) + 16 * k, col = (tid & 15) * 4;
+      const int co = co0 + row, ci = ci0 + col;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (co < L.Cout && ci < L.Cin) {
+        const float* src = w + ((long long)co * taps + tap) * L.Cin + ci;
+        if (vec) {
+          const f32x4 q = *(const f32x4*)src;
+          v[0] = q[0], v[1] = q[1], v[2] = q[2], v[3] = q[3];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (ci + e < L.Cin) v[e] = src[e];
+        }
+        f16* dst = wf + (long long)co * Kpad + tap * L.Cin + ci;
+        if (vec) {
+          typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+          *(f16x4*)dst = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (ci + e < L.Cin) dst[e] = (f16)v[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[row][col + e] = (f16)v[e];
+    }
+    __syncthreads();
+    if (wt) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int cr = (tid >> 3) + 32 * k, c8 = (tid & 7) * 8;
+        const int ci = ci0 + cr, co = co0 + c8;
+        if (ci < L.Cin && co < L.Cout) {  // Cout % 8 == 0: a group of 8 output channels is all-in or all-out
+          f16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = tile[c8 + e][cr];
+          *(f16x8*)(wt + (long long)ci * Kpad_t + (taps - 1 - tap) * L.Cout + co) = o;
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -571,7 +618,7 @@ extern "C" int od_pack_weights_multi(od_ctx* ctx, const float* w, const od_pack_
   OD_REQUIRE(ctx && w && layers && nlayers > 0 && nlayers <= 65535, "od_pack_weights_multi: bad argument");
   // 1024 x 256 threads per layer: the largest layers (4.7 M weights, transposed 2-byte scatter for the backward pack) need the
   // parallelism; the blocks of small layers exit after one test
-  hipLaunchKernelGGL(od_pack_multi_k, dim3(1024, nlayers), dim3(256), 0, (hipStream_t)stream, w, layers);
+  hipLaunchKernelGGL(od_pack_multi_k, dim3(288, nlayers), dim3(256), 0, (hipStream_t)stream, w, layers);
   OD_CHECK_LAUNCH();
   return OD_OK;
 }

@@ -77,6 +77,28 @@ def test_sgd_step_lowers_loss_and_exports(cuda):
     assert int(cnt.min()) >= 0
 
 
+def test_multi_tensor_pack_and_sgd_equal_per_layer_forms(cuda):
+    """The one-launch weight re-pack (LDS-transposed backward layout) and SGD write exactly what the per-layer forms write."""
+    from object_detector_amd.trainer import Trainer
+    B, S = 2, 96
+    params, x, anns = _setup(cuda, B, S)
+    tr = Trainer(params, B, (S, S), device=cuda, lr=0.01, momentum=0.9, loss_scale=256.0)
+    tr.step(torch.from_numpy(x).to(cuda), anns)
+    tr._repack()
+    torch.cuda.synchronize()
+    got = {k: (tr.wf[k].clone(), tr.wb[k].clone() if tr.wb.get(k) is not None else None) for k in tr.wf}
+    for k in tr.wf:
+        tr.wf[k].zero_()
+        if tr.wb.get(k) is not None:
+            tr.wb[k].zero_()
+    tr._repack_per_layer()
+    torch.cuda.synchronize()
+    for k, (f, b) in got.items():
+        assert torch.equal(f, tr.wf[k]), k
+        if b is not None:
+            assert torch.equal(b, tr.wb[k]), k
+
+
 def test_rccl_comm_single_rank(cuda):
     """od_comm_* through the C ABI with a 1-rank communicator (the only topology a 1-GPU box offers): the all-reduce is
     the identity and leaves the gradient buffer bit-identical; DP semantics proper are covered by the gloo test."""
