@@ -288,7 +288,20 @@ __global__ __launch_bounds__(256) void od_wgrad_reduce_k(const od_wgrad_red* __r
   const long long n4 = e.count >> 2;  // counts are multiples of 8 (Cin, Cout % 8 == 0)
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     f32x4 s = *(const f32x4*)(e.slabs + i * 4);
-    for (int k = 1; k < e.nslabs; ++k) {
+    int k = 1;
+    for (; k + 3 < e.nslabs; k += 4) {  // four slab loads in flight, added in ascending slab order
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(e.slabs + (long long)(k + u) * e.count + i * 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s[0] += v[u][0];
+        s[1] += v[u][1];
+        s[2] += v[u][2];
+        s[3] += v[u][3];
+      }
+    }
+    for (; k < e.nslabs; ++k) {
       const f32x4 v = *(const f32x4*)(e.slabs + (long long)k * e.count + i * 4);
       s[0] += v[0];
       s[1] += v[1];
@@ -302,7 +315,7 @@ __global__ __launch_bounds__(256) void od_wgrad_reduce_k(const od_wgrad_red* __r
 
 extern "C" int od_wgrad_reduce_multi(od_ctx* ctx, const od_wgrad_red* table, int nlayers, float* grads, void* stream) {
   OD_REQUIRE(ctx && table && grads && nlayers > 0 && nlayers <= 65535, "od_wgrad_reduce_multi: bad argument");
-  hipLaunchKernelGGL(od_wgrad_reduce_k, dim3(256, nlayers), dim3(256), 0, (hipStream_t)stream, table, grads);
+  hipLaunchKernelGGL(od_wgrad_reduce_k, dim3(nlayers == 1 ? 1024 : 256, nlayers), dim3(256), 0, (hipStream_t)stream, table, grads);
   OD_CHECK_LAUNCH();
   return OD_OK;
 }

@@ -293,6 +293,9 @@ class Trainer:
                 self._slab_ptr[id(n)] = self.wgrad_slabs.data_ptr() + 4 * off
                 off += sp * count
         self._wgrad_table, self._wgrad_n = self._device_table(entries), len(entries)
+        # per-layer reduce right behind the layer's last weight-gradient launch (slabs still in L2 / MALL)
+        self._wgrad_entry = {name: i for i, name in enumerate(per_layer)}
+        self._wgrad_nodes = {name: len(lst) for name, lst in per_layer.items()}
 
     def backward(self):
         """grad_pred -> self.grads (f32, loss-scaled sums over this rank's batch)."""
@@ -302,6 +305,8 @@ class Trainer:
             self._build_wgrad_slabs()
         self.grads.zero_()
         have = set()
+        pending = dict(self._wgrad_nodes)
+        esz = C.sizeof(_lib.WgradRed)
         main = torch.cuda.current_stream(self.device)
         for k, n in enumerate(reversed(self.nodes)):
             Ho, Wo = n.H // n.stride, n.W // n.stride
@@ -353,6 +358,10 @@ class Trainer:
             else:
                 _lib.check(lib.od_conv2d_bwd_weight_slabs(h, x.data_ptr(), dz.data_ptr(), self._slab_ptr[id(n)], self.B, n.H,
                                                           n.W, n.Cin, n.Cout, n.k, n.stride, ws), f"wgrad {n.name}")
+                pending[n.name] -= 1
+                if pending[n.name] == 0:  # every node of the (possibly shared) layer has written its slabs: fixed-order sum
+                    _lib.check(lib.od_wgrad_reduce_multi(h, self._wgrad_table.data_ptr() + esz * self._wgrad_entry[n.name],
+                                                         1, self.grads.data_ptr(), ws), f"wgrad reduce {n.name}")
             if self.wstream is not None:
                 done = torch.cuda.Event()
                 done.record(self.wstream)
@@ -375,9 +384,8 @@ class Trainer:
         if self.wstream is not None:
             main.wait_stream(self.wstream)
             self._wg_done = [None] * len(self.dzs)
-        # conv weight gradients: every layer's per-split slabs summed in a fixed order by ONE launch (no atomics)
-        _lib.check(lib.od_wgrad_reduce_multi(h, self._wgrad_table.data_ptr(), self._wgrad_n, self.grads.data_ptr(), s),
-                   "od_wgrad_reduce_multi")
+        # (conv weight gradients: each layer's per-split slabs were summed in a fixed order right behind its last
+        # weight-gradient launch -- no atomics, and the slabs are still cache-resident when they are read back)
         # shared-layer BN gradients were accumulated over the three levels inside od_bn_bwd
         return self.grads
 
