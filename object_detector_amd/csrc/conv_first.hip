@@ -115,18 +115,23 @@ namespace {
 constexpr int GTH = 8, GLH = GTH + 2;  // this kernel's own tile: 8 rows (one per 32-thread part) x 32 pixels
 __global__ __launch_bounds__(256) void od_conv_first_wgrad(const uint8_t* __restrict__ x, const f16* __restrict__ dz,
                                                            float* __restrict__ dw, int H, int W, float in_scale) {
-  __shared__ uint8_t tile[GLH * LW * 4];
+  // halo tile converted to f32 ONCE ([row][pixel][4], 4th = 0): the inner loop is one 16-B LDS read + 3 FMAs per tap
+  // instead of a byte read + convert + FMA per (tap, channel)
+  __shared__ __attribute__((aligned(16))) float tile[GLH * LW * 4];
   __shared__ float red[8][32][28];
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * GTH, b = blockIdx.z;
-  for (int i = tid; i < GLH * LW; i += 256) tile[i * 4 + 3] = 0;
-  for (int i = tid; i < GLH * ROWB; i += 256) {
-    const int r = i / ROWB, bt = i - r * ROWB;
-    const int px = bt / 3, c = bt - px * 3;
+  for (int i = tid; i < GLH * LW; i += 256) {
+    const int r = i / LW, px = i - r * LW;
     const int gy = y0 - 1 + r, gx = x0 - 1 + px;
-    uint8_t v = 0;
-    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = x[((long long)(b * H + gy) * W + gx) * 3 + c];
-    tile[(r * LW + px) * 4 + c] = v;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+      const uint8_t* src = x + ((long long)(b * H + gy) * W + gx) * 3;
+      v[0] = (float)src[0];
+      v[1] = (float)src[1];
+      v[2] = (float)src[2];
+    }
+    *(f32x4*)(tile + i * 4) = v;
   }
   __syncthreads();
   const int co = tid & 31, part = tid >> 5;  // part = tile row (8 rows of 32 pixels)
@@ -135,15 +140,17 @@ __global__ __launch_bounds__(256) void od_conv_first_wgrad(const uint8_t* __rest
   for (int k = 0; k < 27; ++k) acc[k] = 0.f;
   const int gy = y0 + part;
   if (gy < H) {
-    for (int xx = 0; xx < TW; ++xx) {
-      const int gx = x0 + xx;
-      if (gx >= W) break;
-      const float d = (float)dz[((long long)(b * H + gy) * W + gx) * 32 + co];
-      const uint8_t* pb = tile + (part * LW + xx) * 4;
+    const int nx = min(TW, W - x0);
+    const f16* dzp = dz + ((long long)(b * H + gy) * W + x0) * 32 + co;
+    for (int xx = 0; xx < nx; ++xx) {
+      const float d = (float)dzp[xx * 32];
+      const float* pb = tile + (part * LW + xx) * 4;
 #pragma unroll
-      for (int k = 0; k < 27; ++k) {
-        const int tap = k / 3, c = k - tap * 3;
-        acc[k] += d * (float)pb[((tap / 3) * LW + tap % 3) * 4 + c];
+      for (int tap = 0; tap < 9; ++tap) {
+        const f32x4 v = *(const f32x4*)(pb + ((tap / 3) * LW + tap % 3) * 4);
+        acc[tap * 3 + 0] += d * v[0];
+        acc[tap * 3 + 1] += d * v[1];
+        acc[tap * 3 + 2] += d * v[2];
       }
     }
   }
