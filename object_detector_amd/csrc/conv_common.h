@@ -20,6 +20,7 @@ struct ConvKP {
   int mtiles, ntiles;
   int splitk, steps_per_split;  // split-K (small-M layers): each workgroup reduces a K range, f32 atomics into ws
   float* ws;                    // [splitk][M][Cout] f32 partial slabs; od_conv_finish sums them and applies the epilogue
+  int Mq;             // transposed mode: B*Hs*Ws source positions (rows per parity class)
   int tconv, Hs, Ws;  // transposed (backward-data of a stride-2 conv): x is [B,Hs,Ws,Cin], gathered through a 2x zero-upsampled view
   unsigned x_bytes, w_bytes;  // extents of x / packed w (buffer-addressed loaders: out-of-range lanes read zeros)
   int dbg;  // tuning ablations (OD_CONV_DEBUG): bit0 = skip the DMA, bit1 = skip fragment reads + MFMA
@@ -61,15 +62,19 @@ static __device__ __forceinline__ void wait_vmcnt() {
 }
 
 
-// transposed mode: GEMM row m' -> linear output pixel index (b*HoWo + y*Wo + x).  Rows are ordered parity class by
-// parity class: m' = cls * M/4 + (b, i, j) over the SOURCE grid [Hs, Ws], pixel (y, x) = (2i + (cls >> 1), 2j + (cls & 1)).
-static __device__ __forceinline__ unsigned od_tconv_pixel(const ConvKP& p, unsigned m) {
-  const unsigned Mq = (unsigned)p.M >> 2;
-  const unsigned cls = m / Mq, idx = m - cls * Mq;
+// transposed mode: GEMM row m' -> linear output pixel index (b*HoWo + y*Wo + x), or -1 for a padding row.  Rows are
+// grouped by output parity class tile by tile: tile t of BM rows belongs to class t & 3 and covers positions
+// [(t >> 2)*BM, +BM) of the SOURCE grid [B, Hs, Ws]; pixel (y, x) = (2i + (cls >> 1), 2j + (cls & 1)).  The four classes of
+// one source block are neighbours in the tile order (same XCD / L2: the dZ block is fetched once, and the two 64..128-B
+// halves of an output line are written close together); p.M is the padded row count 4 * ceil(Mq / BM) * BM.
+static __device__ __forceinline__ int od_tconv_pixel(const ConvKP& p, unsigned m, unsigned BM) {
+  const unsigned t = m / BM, r = m - t * BM;
+  const unsigned cls = t & 3u, idx = (t >> 2) * BM + r;
+  if (idx >= (unsigned)p.Mq) return -1;
   const unsigned HsWs = (unsigned)(p.Hs * p.Ws);
-  const unsigned b = idx / HsWs, r = idx - b * HsWs;
-  const unsigned i = r / (unsigned)p.Ws, j = r - i * (unsigned)p.Ws;
-  return b * (unsigned)p.HoWo + (2u * i + (cls >> 1)) * (unsigned)p.Wo + 2u * j + (cls & 1u);
+  const unsigned b = idx / HsWs, q = idx - b * HsWs;
+  const unsigned i = q / (unsigned)p.Ws, j = q - i * (unsigned)p.Ws;
+  return (int)(b * (unsigned)p.HoWo + (2u * i + (cls >> 1)) * (unsigned)p.Wo + 2u * j + (cls & 1u));
 }
 
 // ---- epilogue shared by every conv kernel: accumulators -> LDS staging (one wave-row of the tile at a time) ->
@@ -107,8 +112,8 @@ static __device__ __forceinline__ void conv_epilogue(const ConvKP& p, char* smem
       for (int ps = 0; ps < NPASS; ++ps) {
         int m = m0 + wr * WTM + ps * RPP + tid / CH;
         f16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (m < p.M && n < p.Cout) {
-          if (p.tconv) m = (int)od_tconv_pixel(p, (unsigned)m);
+        if (p.tconv && m < p.M) m = od_tconv_pixel(p, (unsigned)m, WM * MT * 16);
+        if (m >= 0 && m < p.M && n < p.Cout) {
           long long roff;
           if (p.res_mode == OD_RES_SAME) {
             roff = (long long)m * p.Cout + n;
@@ -156,8 +161,8 @@ static __device__ __forceinline__ void conv_epilogue(const ConvKP& p, char* smem
     for (int ps = 0; ps < NPASS; ++ps) {
       const int row = ps * RPP + tid / CH;
       int m = m0 + wr * WTM + row;
-      if (m < p.M && n < p.Cout) {
-        if (p.tconv) m = (int)od_tconv_pixel(p, (unsigned)m);
+      if (p.tconv && m < p.M) m = od_tconv_pixel(p, (unsigned)m, WM * MT * 16);
+      if (m >= 0 && m < p.M && n < p.Cout) {
         const f32x4 v0 = *(const f32x4*)(stg + row * SLD + c8);
         const f32x4 v1 = *(const f32x4*)(stg + row * SLD + c8 + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};

@@ -101,8 +101,8 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), MINW) void od_conv_ig
   for (int rd = 0; rd < AR; ++rd) {
     int m = m0 + rd * RPR + rr;
     a_vmask[rd] = 0u;
-    if (m < p.M) {
-      if (p.tconv) m = (int)od_tconv_pixel(p, (unsigned)m);  // rows are grouped by output parity class (see below)
+    if (p.tconv && m < p.M) m = od_tconv_pixel(p, (unsigned)m, BM);  // rows are grouped by output parity class (see below)
+    if (m >= 0 && m < p.M) {
       const unsigned b = (unsigned)m / (unsigned)p.HoWo;
       const unsigned pix = (unsigned)m - b * (unsigned)p.HoWo;
       const unsigned ho = pix / (unsigned)p.Wo;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), MINW) void od_conv_ig
 
   // Transposed mode (backward-data of a stride-2 conv): an output pixel only receives the taps whose source position in
   // the zero-upsampled view is even -- 1, 2, 2 or 4 of the 9, by the parity of (y, x).  The rows of the GEMM are ordered
-  // parity class by parity class (od_tconv_pixel), so a tile's rows (almost always) share their class and the taps that
+  // tile by tile in parity classes (od_tconv_pixel), so a tile's rows share their class and the taps that
   // are zero for EVERY row of the tile are skipped as whole K steps: 2.25 instead of 9 taps on average.  Skipped steps
   // only add exact zeros, so the result is bit-identical to the un-skipped walk.
   unsigned tmask = 0x1FFu;
@@ -554,6 +554,7 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
   const bool use_pw = cfg == cfg_pw;
   const bool use_e8 = cfg >= cfg_e8;
   const bool use_win = cfg >= kNumCfgs && !use_pw && !use_e8;
+  OD_REQUIRE(!tconv || !(use_win || use_pw || use_e8), "od_conv2d_fwd: transposed mode runs on the table kernels only (tile_cfg %d)", cfg);
   TileCfg tc = g_cfgs[(use_win || use_pw || use_e8) ? 0 : cfg];
 
   ConvKP p;
@@ -665,6 +666,12 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
     tc.lds = lds;
   }
   p.mtiles = od_ceil_div(M, tc.BM);
+  p.Mq = 0;
+  if (tconv) {  // rows per parity class padded to whole tiles, classes interleaved tile by tile (od_tconv_pixel)
+    p.Mq = M / 4;
+    p.mtiles = 4 * od_ceil_div(p.Mq, tc.BM);
+    p.M = p.mtiles * tc.BM;
+  }
   p.ntiles = od_ceil_div(d->Cout, tc.BN);
   // split-K for layers that cannot fill the chip with output tiles (batch-1 inference): every K-range workgroup writes
   // its partial tile to its own slab of the caller's f32 workspace; splitk == 0 lets the library choose
