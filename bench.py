@@ -135,6 +135,20 @@ def train_bench(a, rank, world, dev):
         torch.distributed.destroy_process_group()
 
 
+def _workgroups(kernel_name, M, N):
+    """Workgroups of one launch, from the tile shape in the kernel's template arguments (0 = unknown)."""
+    import re
+    m = re.match(r"od_conv_8ph<\d+, (\d+)", kernel_name)
+    if m:
+        bm, bn = 32 * (4 + int(m.group(1))), 256
+    else:
+        m = re.match(r"od_conv_igemm<(\d+), (\d+)", kernel_name)
+        if not m:
+            return 0
+        bm, bn = int(m.group(1)), int(m.group(2))
+    return -(-M // bm) * -(-N // bn)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -208,6 +222,19 @@ def main():
     dom = max(groups, key=lambda k: groups[k]["ms"])
     g = groups[dom]
     achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    # how much of the chip one launch of that kernel occupies: with batches in flight the plan deliberately picks tiles by
+    # CU x time, so e.g. a stage-4 launch of the 256-row kernel is 100 workgroups on 256 CUs (the rest run other batches)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    fill_t, fill_n = 0.0, 0.0
+    for t, nm, inf in zip(ms, names, info):
+        if nm != dom:
+            continue
+        wg = _workgroups(nm, inf["shape"][0], inf["shape"][1])
+        f = min(1.0, wg / cus) if wg else 1.0
+        fill_t += float(t) * f
+        fill_n += f
+    cu_fill = fill_n / g["n"]
+    achieved_active = g["flops"] / (fill_t * 1e-3) / 1e12 if fill_t > 0 else achieved
     net_ms = float(ms.sum())
     # HBM-side bytes per launch of that kernel from the committed PMC passes (profiles/, rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE with the gfx950 x2 FETCH correction); PMC cannot be collected from inside this process -> null if absent
@@ -259,6 +286,7 @@ def main():
                          "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F16_TFLOPS, 4),
                          "avg_launch_us": round(g["ms"] / g["n"] * 1e3, 2),
+                         "cu_fill": round(cu_fill, 3), "achieved_on_occupied_cus": round(achieved_active, 2),
                          "algorithmic_gflop_per_launch": round(g["flops"] / g["n"] / 1e9, 3),
                          "network_ms_per_batch": round(net_ms, 4),
                          "network_tflops": round(sum(i["flops"] for i in info) / (net_ms * 1e-3) / 1e12, 2),
