@@ -16,11 +16,12 @@ def _act_t(a, act, alpha):
     return a
 
 
-@pytest.mark.parametrize("C,act", [(32, "leaky"), (256, "elu"), (1024, "leaky"), (208, None)])
-def test_bn_forward_backward(cuda, C, act):
+@pytest.mark.parametrize("shape", [(3, 6, 10), (4, 37, 29)], ids=["m180", "m4292"])  # one workgroup / several partial rows + ragged unroll tails
+@pytest.mark.parametrize("C,act", [(32, "leaky"), (64, "leaky"), (256, "elu"), (1024, "leaky"), (208, None)])
+def test_bn_forward_backward(cuda, C, act, shape):
     from object_detector_amd import train_ops as T
     rng = np.random.default_rng(C)
-    B, H, W = 3, 6, 10
+    B, H, W = shape
     alpha = 0.1 if act == "leaky" else 1.0
     z = rng.normal(0.3, 1.5, (B, H, W, C)).astype(np.float16)
     gamma = rng.uniform(0.5, 1.5, C).astype(np.float32)
