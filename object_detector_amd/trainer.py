@@ -108,11 +108,48 @@ class Trainer:
         self.dz = self.dzs[0]
         self.wstream = torch.cuda.Stream(device=dev) if self.use_wstream else None
         self._wg_done = [None] * len(self.dzs)
+        # gradient exchange: buckets of whole layers from the END of the flat buffer (the order backward finishes them),
+        # each all-reduced on its own stream as soon as its last layer is final -> the RCCL traffic overlaps the rest of
+        # the backward pass.  OD_TRAIN_BUCKET_MB=0 -> one all-reduce after backward.
+        self.bucket_mb = float(os.environ.get("OD_TRAIN_BUCKET_MB", "32"))
+        self.cstream = torch.cuda.Stream(device=dev) if (self.comm is not None and self.bucket_mb > 0) else None
+        self._buckets = self._make_buckets(int(self.bucket_mb * (1 << 20) / 4)) if self.cstream is not None else []
+        self._next_bucket = 0
         mxc = max(self.lib.od_bn_workspace_bytes(self.B * (n.H // n.stride) * (n.W // n.stride), n.Cout) + 2 * n.Cout * 4
                   for n in self.nodes)
         self.bn_ws = torch.empty(mxc, dtype=torch.uint8, device=dev)
 
     # ------------------------------------------------------------------------------------------------------------
+    def _make_buckets(self, min_elems):
+        """[(lo, hi, {layer names})] in the order backward completes them: contiguous ranges of the flat gradient buffer
+        cut at layer boundaries, walking from the last layer to the first."""
+        layers = []  # (lo, hi, name) per layer, in buffer order
+        for name in self.specs:
+            offs = [(o, o + (n + 3) // 4 * 4) for (nm, _k), (o, n) in self.seg.items() if nm == name]
+            layers.append((min(o for o, _ in offs), max(h for _, h in offs), name))
+        buckets, hi, names = [], self.n_flat, set()
+        for lo, _h, name in reversed(layers):
+            names.add(name)
+            if hi - lo >= min_elems:
+                buckets.append((lo, hi, names))
+                hi, names = lo, set()
+        if names:
+            buckets.append((0, hi, names))
+        return buckets
+
+    def _launch_ready_buckets(self, done_layers, main):
+        """All-reduce every not-yet-launched bucket whose layers are all final (in order), on the communication stream."""
+        while self._next_bucket < len(self._buckets):
+            lo, hi, names = self._buckets[self._next_bucket]
+            if not names <= done_layers:
+                return
+            self.cstream.wait_stream(main)  # BatchNorm / bias gradients of these layers
+            if self.wstream is not None:
+                self.cstream.wait_stream(self.wstream)  # their weight gradients (slab reduce)
+            _lib.check(self.lib.od_allreduce(self.comm, self.grads.data_ptr() + 4 * lo, hi - lo, _lib.OD_DT_F32,
+                                             C.c_void_p(self.cstream.cuda_stream)), "od_allreduce(bucket)")
+            self._next_bucket += 1
+
     def view(self, buf, name, kind):
         o, n = self.seg[(name, kind)]
         return buf[o:o + n]
@@ -308,6 +345,10 @@ class Trainer:
         pending = dict(self._wgrad_nodes)
         esz = C.sizeof(_lib.WgradRed)
         main = torch.cuda.current_stream(self.device)
+        done_layers = set()
+        self._next_bucket = 0
+        if self.cstream is not None:
+            self.cstream.wait_stream(main)  # grads.zero_() above
         for k, n in enumerate(reversed(self.nodes)):
             Ho, Wo = n.H // n.stride, n.W // n.stride
             M = self.B * Ho * Wo
@@ -366,6 +407,10 @@ class Trainer:
                 done = torch.cuda.Event()
                 done.record(self.wstream)
                 self._wg_done[slot] = done
+            if n.first or pending[n.name] == 0:
+                done_layers.add(n.name)
+                if self.cstream is not None:
+                    self._launch_ready_buckets(done_layers, main)
             if n.first or not n.need_dx:
                 continue
             g = self._grad(n.x)
@@ -390,7 +435,12 @@ class Trainer:
         return self.grads
 
     def allreduce(self):
-        """Sum the flat f32 gradient buffer over the data-parallel ranks (ONE collective per step: 47 M floats)."""
+        """Sum the flat f32 gradient buffer over the data-parallel ranks: bucketed all-reduces launched during backward on
+        the communication stream (RCCL through the C ABI), or one collective after backward (47 M floats)."""
+        if self.cstream is not None:  # bucketed: every bucket was launched during backward, join the communication stream
+            assert self._next_bucket == len(self._buckets), "a gradient bucket was never launched"
+            torch.cuda.current_stream(self.device).wait_stream(self.cstream)
+            return
         if self.world <= 1:
             return
         if self.comm is not None:
