@@ -137,3 +137,32 @@ def test_batches_in_flight_match_sequential(cuda):
     for b, (rkf, rkc) in enumerate(ref):
         for i in range(2):
             assert np.array_equal(preds[2 * b + i].flat_indices, rkf[i, :rkc[i]])
+
+
+def test_predict_from_files_with_decode_pool(cuda, tmp_path, monkeypatch):
+    """predict() on image files: the decode thread pool + pinned staging buffers return, in input order, exactly what the
+    single-threaded path returns (11 files of mixed sizes = 5 full batches + a partial one + buffer rotation)."""
+    from PIL import Image
+    from object_detector_amd.detector import ObjectDetector
+    rng = np.random.default_rng(5)
+    paths = []
+    for i in range(11):
+        h, w = int(rng.integers(60, 200)), int(rng.integers(60, 200))
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        pth = tmp_path / f"im{i}.png"
+        Image.fromarray(a).save(pth)
+        paths.append(str(pth))
+    od = ObjectDetector.synthetic(2, (96, 96), seed=4, device=cuda, use_multi_gpu=False, n_inflight=3)
+    monkeypatch.setenv("OD_DECODE_THREADS", "1")
+    one = od.predict(paths, conf_threshold=0.01)
+    monkeypatch.setenv("OD_DECODE_THREADS", "8")
+    many = od.predict(paths, conf_threshold=0.01)
+    again = od.predict(paths[::-1], conf_threshold=0.01)[::-1]
+    monkeypatch.setenv("OD_DECODE_PROCS", "2")  # spawned decode workers + shared-memory staging block
+    procs = od.predict(paths, conf_threshold=0.01)
+    od.close_decode_pool()
+    assert len(one) == len(many) == len(procs) == 11
+    for a, b, c, d in zip(one, many, again, procs):
+        assert np.array_equal(a.flat_indices, b.flat_indices) and np.array_equal(a.bboxes, b.bboxes)
+        assert np.array_equal(a.flat_indices, c.flat_indices)
+        assert np.array_equal(a.flat_indices, d.flat_indices) and np.array_equal(a.bboxes, d.bboxes)
