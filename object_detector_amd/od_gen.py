@@ -148,12 +148,17 @@ def apply_pixels_device(images, params, out_hw, device):
 
 
 class Generator:
-    def __init__(self, input_size, preprocess_input=None, encode_truth=None, random_erasing=True, device=None):
+    def __init__(self, input_size, preprocess_input=None, encode_truth=None, random_erasing=True, device=None, workers=None):
         self.input_size = tuple(int(v) for v in input_size)
         self.preprocess_input = preprocess_input
         self.encode_truth = encode_truth
         self.random_erasing = random_erasing
         self.device = device  # e.g. "cuda:0": pixel work runs in od_augment_batch (K14); None: host path (PIL)
+        # image decode (and the host augmentation) of a batch runs on a thread pool, the NEXT batch's decode is already in
+        # flight while this one is consumed; augmentation parameters are still drawn in index order on the calling thread,
+        # so the stream of batches is identical for any worker count
+        import os
+        self.workers = int(workers if workers is not None else os.environ.get("OD_GEN_WORKERS", min(8, os.cpu_count() or 1)))
 
     def _load(self, x):
         if isinstance(x, np.ndarray):
@@ -175,22 +180,30 @@ class Generator:
         steps = max(1, math.ceil(n / batch_size))
 
         def it():
+            from concurrent.futures import ThreadPoolExecutor
             rng = np.random.default_rng(seed)
+            pool = ThreadPoolExecutor(max_workers=self.workers) if self.workers > 1 else None
+
+            def load_batch(idx):
+                return [pool.submit(self._load, X[i]) for i in idx] if pool is not None else None
+
             while True:
                 order = rng.permutation(n) if shuffle else np.arange(n)
-                for s in range(0, n, batch_size):
-                    idx = order[s:s + batch_size]
+                batches = [order[s:s + batch_size] for s in range(0, n, batch_size)]
+                nxt = load_batch(batches[0])
+                for bi, idx in enumerate(batches):
+                    futs, nxt = nxt, (load_batch(batches[bi + 1]) if bi + 1 < len(batches) else None)
+                    raw = [f.result() for f in futs] if futs is not None else [self._load(X[i]) for i in idx]
+                    prm = [sample_params(rng, y[i], self.random_erasing) if data_augmentation else AugParams() for i in idx]
                     if self.device is not None:
-                        raw = [self._load(X[i]) for i in idx]
-                        prm = [sample_params(rng, y[i], self.random_erasing) if data_augmentation else AugParams()
-                               for i in idx]
                         xb = apply_pixels_device(raw, prm, self.input_size, self.device).cpu().numpy()
-                        anns = [ObjectsAnnotation(y[i].path, self.input_size[1], self.input_size[0], y[i].classes,
-                                                  transform_boxes(y[i].bboxes, p), y[i].difficults)
-                                for i, p in zip(idx, prm)]
+                    elif pool is not None:
+                        xb = np.stack(list(pool.map(lambda ip: apply_pixels_host(ip[0], ip[1], self.input_size), zip(raw, prm))))
                     else:
-                        imgs, anns = zip(*(self.generate(X[i], y[i], rng, data_augmentation) for i in idx))
-                        xb = np.stack(imgs)
+                        xb = np.stack([apply_pixels_host(img, p, self.input_size) for img, p in zip(raw, prm)])
+                    anns = [ObjectsAnnotation(y[i].path, self.input_size[1], self.input_size[0], y[i].classes,
+                                              transform_boxes(y[i].bboxes, p), y[i].difficults)
+                            for i, p in zip(idx, prm)]
                     if self.preprocess_input is not None:
                         xb = self.preprocess_input(xb)
                     yb = self.encode_truth(list(anns)) if self.encode_truth is not None else list(anns)

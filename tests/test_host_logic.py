@@ -178,6 +178,24 @@ def test_generator_host_path(tmp_path):
     assert (tmp_path / "o" / "x.jpg").exists()
 
 
+def test_generator_stream_independent_of_worker_count(tmp_path):
+    """Decode / host augmentation run on a thread pool with the next batch prefetched; parameters are drawn in index order
+    on the calling thread, so the batches are identical for any worker count."""
+    import pytoolkit as tk
+    from object_detector_amd import od_gen
+    _write_voc(tmp_path)
+    X, y = tk.data.voc.load_07_test(tmp_path)
+    outs = []
+    for workers in (1, 4):
+        gen = od_gen.create_generator((64, 96), workers=workers)
+        g, _steps = gen.flow(X, y, batch_size=2, data_augmentation=True, shuffle=True, seed=11)
+        outs.append([next(g) for _ in range(5)])
+    for (xa, ya), (xb, yb) in zip(*outs):
+        assert np.array_equal(xa, xb) and len(ya) == len(yb)
+        for a, b in zip(ya, yb):
+            assert np.array_equal(a.bboxes, b.bboxes) and np.array_equal(a.classes, b.classes)
+
+
 def test_tk_surface_matches_reference_scripts():
     """every tk.* symbol the four reference scripts touch exists."""
     import pytoolkit as tk
