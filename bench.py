@@ -49,7 +49,16 @@ def cpu_baseline(size, seconds):
     from oracle import network as onet
     from oracle import nms as onms
     from oracle import postprocess as opp
-    cores = torch.get_num_threads()
+    # threads actually usable: the affinity mask capped by the cgroup CPU quota (a 16-core share of a 256-thread host ran
+    # torch's default 128 threads ~6x slower than 16 threads do)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    torch.set_num_threads(cores)
     params = onet.init_weights(seed=2)
     runner = onet.Runner(params, storage="f32")
     priors = opp.make_priors((size, size))
