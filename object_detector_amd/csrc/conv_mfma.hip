@@ -54,7 +54,7 @@ template <int BM, int BN, int BK, int STAGES, int WM, int WN, int KS, int MINW, 
 __global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), MINW) void od_conv_igemm(ConvKP p) {
   using Cf = ConvCfg<BM, BN, BK, STAGES, WM, WN, SPEC>;
   constexpr int NT = Cf::NT, AR = Cf::AR, BR = Cf::BR, RPR = Cf::RPR, ROWB = Cf::ROWB;
-  constexpr int WTM = Cf::WTM, WTN = Cf::WTN, MT = Cf::MT, NTL = Cf::NTL, SLD = Cf::SLD;
+  constexpr int WTM = Cf::WTM, WTN = Cf::WTN, MT = Cf::MT, NTL = Cf::NTL;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
