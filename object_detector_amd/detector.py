@@ -95,7 +95,7 @@ class ObjectDetector:
         self.num_classes, _, _ = W.infer_arch(params)
         kw = {} if prior_wh is None else {"prior_wh": prior_wh}
         self.pb = PriorBoxes(self.input_size, self.num_classes, device=self.device, **kw)
-        n = int(os.environ.get("OD_INFLIGHT", 3 if n_inflight is None else n_inflight))
+        n = int(n_inflight) if n_inflight is not None else int(os.environ.get("OD_INFLIGHT", 3))  # explicit argument wins
         self.net = Net(params, self.batch_size, self.input_size, device=self.device, overlapped=n > 1)
         assert self.net.P == len(self.pb)
         self.post = Postprocessor(self.batch_size, self.net.P, self.num_classes, self.pb.pb_locs, device=self.device,
