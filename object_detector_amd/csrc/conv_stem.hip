@@ -4,12 +4,16 @@
 // network, written by one launch and read back by the next) never leaves the CU.
 //
 // PERSISTENT workgroups (8 waves, one per CU) walk 16x16-pixel output tiles:
-//   1. the 35x35 uint8 input window of the NEXT tile is fetched into registers while this tile computes and dropped into
-//      the other LDS buffer at the end of the tile ([row][pixel][4 B], 4th byte 0, zeros outside the image)
-//   2. producer = od_conv_first's arithmetic on the 33x33 window of first-layer pixels: the A fragment (K = 27 padded to 32)
-//      is built in registers from the uint8 window, 2 MFMAs per 16 pixels, scale/bias/activation, ONE rounding to f16,
-//      16-byte LDS writes (weight rows permuted so that a lane holds 8 consecutive channels); pixels outside the image
-//      are written as 0 = the zero padding the stride-2 convolution sees in the two-layer network
+//   1. the 35x35 uint8 input window of the NEXT tile is fetched into registers while this tile computes, converted to
+//      f16 ONCE per pixel and dropped into the other LDS buffer at the end of the tile ([row][pixel][4 x f16], 4th = 0,
+//      zeros outside the image)
+//   2. producer = od_conv_first's convolution on the 33x33 window of first-layer pixels with the K axis laid out as
+//      k = tap*4 + channel: a lane's 8 k's are two whole window pixels = two 8-byte LDS reads, no per-element convert
+//      or pack (the byte-window form spent 28 VALU instructions per fragment on that and made the kernel VALU-issue
+//      bound); taps 0..7 fill one 32-deep MFMA, tap 8 a second one (4 of 32 k's used: the matrix pipe is idle here
+//      anyway); scale/bias/activation, ONE rounding to f16, 16-byte LDS writes (weight rows permuted so that a lane holds
+//      8 consecutive channels); pixels outside the image are written as 0 = the zero padding the stride-2 convolution
+//      sees in the two-layer network
 //   3. consumer = 3x3 stride 2 from that window.  The window is stored DE-INTERLEAVED (even and odd columns as two
 //      planes per row) so that the 16 pixels x0 + 2*l + dx of a fragment are 16 consecutive 64-byte rows: the
 //      chunk ^ 3*((row>>2)&1) swizzle is then conflict-free for every tap (a stride-2 walk over interleaved rows is
@@ -44,7 +48,7 @@ struct StemKP {
 // (28 k VALU instructions per SIMD for the first layer alone, profiles/r01/conv_stem_analysis.txt), and one wave per
 // SIMD cannot issue them faster than one per 4-5 cycles).
 constexpr int S_UW = 35;                       // uint8 window edge
-constexpr int S_UBYTES = 4992;                 // 35*35*4 = 4900, rounded up to 128
+constexpr int S_UBYTES = 9856;                 // 35*35 pixels x 4 f16 = 9800, rounded up to 128
 constexpr int S_TW = 33, S_TROW = 34;          // first-layer window edge; LDS rows per window row (17 even + 17 odd slots)
 constexpr int S_NTP = S_TW * S_TW;             // 1089 producer pixels = 69 m-fragments (last one ragged)
 constexpr int S_NTF = (S_NTP + 15) / 16;
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void od_stem(StemKP p, int ntiles) {
       for (int tap = 0; tap < 9; ++tap) s_buffer_dma(rs_w3, voff, tap * 64, smem + S_OFF_W3 + tap * S_W3TAP + wave * 1024);
     }
   }
-  // uint8 windows: the 4th byte of every pixel is the zero that the padded k = 27..31 of the A fragment read
+  // input windows: the 4th f16 of every pixel stays the zero that k = tap*4 + 3 of the A fragment reads
   for (int i = tid; i < 2 * S_UBYTES / 4; i += 512) ((int*)(smem + S_OFF_U))[i] = 0;
 
   // per-thread byte slots of a window: i = r*512 + tid -> (row, byte in row); row = 105 contiguous source bytes
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void od_stem(StemKP p, int ntiles) {
     const int uy = i / (S_UW * 3), bt = i - uy * (S_UW * 3);
     const int ux = bt / 3, c = bt - ux * 3;
     u_src[r] = i < S_UW * S_UW * 3 ? (uy << 16) | (ux << 8) | c : -1;
-    u_dst[r] = (uy * S_UW + ux) * 4 + c;
+    u_dst[r] = (uy * S_UW + ux) * 8 + c * 2;
   }
   uint8_t ubuf[S_UROUNDS];
   auto fetch_u = [&](int t) {  // global -> registers
@@ -124,25 +128,26 @@ __global__ __launch_bounds__(512, 2) void od_stem(StemKP p, int ntiles) {
   auto store_u = [&](int buf) {  // registers -> LDS
 #pragma unroll
     for (int r = 0; r < S_UROUNDS; ++r)
-      if (u_src[r] >= 0) *(uint8_t*)(smem + S_OFF_U + buf * S_UBYTES + u_dst[r]) = ubuf[r];
+      if (u_src[r] >= 0) *(f16*)(smem + S_OFF_U + buf * S_UBYTES + u_dst[r]) = (f16)(float)ubuf[r];
   };
 
   // first-layer weights (A operand; row r of n-tile t = channel (r/4)*8 + t*4 + r%4, so a lane ends up with 8 consecutive
-  // channels), the LDS byte offsets of this lane's 8 k's relative to its pixel, scale / bias
-  f16x8 wf[2];
+  // channels) re-gathered from the [32][tap*3 + c] pack into the k = tap*4 + c layout: wfa = taps 0..7, wfb = tap 8
+  f16x8 wfa[2], wfb[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int ch = (l15 >> 2) * 8 + t * 4 + (l15 & 3);
-    wf[t] = *(const f16x8*)(p.w0 + ch * 32 + lq * 8);
-  }
-  int koff[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int k = lq * 8 + j;
-    const int tap = k / 3, c = k - tap * 3;
-    const int dy = tap / 3, dx = tap - dy * 3;
-    koff[j] = k < 27 ? (dy * S_UW + dx) * 4 + c : 3;
+    for (int j = 0; j < 8; ++j) {
+      const int tap = 2 * lq + (j >> 2), c = j & 3;
+      wfa[t][j] = c < 3 ? p.w0[ch * 32 + tap * 3 + c] : (f16)0.f;
+      wfb[t][j] = (lq == 0 && j < 3) ? p.w0[ch * 32 + 24 + j] : (f16)0.f;
+    }
   }
+  // byte offsets of this lane's two taps (and of tap 8) relative to its window pixel
+  const int ko0 = (((2 * lq) / 3) * S_UW + (2 * lq) % 3) * 8;
+  const int ko1 = (((2 * lq + 1) / 3) * S_UW + (2 * lq + 1) % 3) * 8;
+  constexpr int ko8 = (2 * S_UW + 2) * 8;
   float sc0[8], bi0[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -178,13 +183,18 @@ __global__ __launch_bounds__(512, 2) void od_stem(StemKP p, int ntiles) {
       const int wp = f * 16 + l15;
       const int wpc = wp < S_NTP ? wp : S_NTP - 1;
       const int wy = wpc / S_TW, wx = wpc - wy * S_TW;
-      const char* pbase = uw + (wy * S_UW + wx) * 4;
-      f16x8 xf;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) xf[j] = (f16)(float)(*(const uint8_t*)(pbase + koff[j]));
+      const char* pbase = uw + (wy * S_UW + wx) * 8;
+      typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+      const f16x4 q0 = *(const f16x4*)(pbase + ko0), q1 = *(const f16x4*)(pbase + ko1);
+      const f16x4 q8 = *(const f16x4*)(pbase + ko8);
+      const f16x8 xf = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+      const f16 z = (f16)0.f;
+      const f16x8 xg = lq == 0 ? f16x8{q8[0], q8[1], q8[2], q8[3], z, z, z, z} : f16x8{z, z, z, z, z, z, z, z};
       f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], xf, a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1], xf, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfa[0], xf, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfa[1], xf, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfb[0], xg, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfb[1], xg, a1, 0, 0, 0);
       if (wp < S_NTP) {
         const int iy = 2 * y0 - 1 + wy, ix = 2 * x0 - 1 + wx;
         const bool inside = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
