@@ -121,21 +121,11 @@ class Trainer:
 
     # ------------------------------------------------------------------------------------------------------------
     def _make_buckets(self, min_elems):
-        """[(lo, hi, {layer names})] in the order backward completes them: contiguous ranges of the flat gradient buffer
-        cut at layer boundaries, walking from the last layer to the first."""
         layers = []  # (lo, hi, name) per layer, in buffer order
         for name in self.specs:
             offs = [(o, o + (n + 3) // 4 * 4) for (nm, _k), (o, n) in self.seg.items() if nm == name]
             layers.append((min(o for o, _ in offs), max(h for _, h in offs), name))
-        buckets, hi, names = [], self.n_flat, set()
-        for lo, _h, name in reversed(layers):
-            names.add(name)
-            if hi - lo >= min_elems:
-                buckets.append((lo, hi, names))
-                hi, names = lo, set()
-        if names:
-            buckets.append((0, hi, names))
-        return buckets
+        return make_buckets(layers, self.n_flat, min_elems)
 
     def _launch_ready_buckets(self, done_layers, main):
         """All-reduce every not-yet-launched bucket whose layers are all final (in order), on the communication stream."""
@@ -501,6 +491,22 @@ class Trainer:
             out[name + ".mean"] = self.run_mean[name].cpu().numpy()
             out[name + ".var"] = self.run_var[name].cpu().numpy()
         return out
+
+
+def make_buckets(layers, n_flat, min_elems):
+    """Gradient buckets for the overlapped all-reduce.  layers: [(lo, hi, name)] in buffer (= forward) order, contiguous
+    and covering [0, n_flat).  -> [(lo, hi, {layer names})] in the order backward completes them: contiguous ranges cut
+    at layer boundaries, walking from the last layer to the first, each at least `min_elems` long (the last one takes
+    whatever is left)."""
+    buckets, hi, names = [], n_flat, set()
+    for lo, _h, name in reversed(layers):
+        names.add(name)
+        if hi - lo >= min_elems:
+            buckets.append((lo, hi, names))
+            hi, names = lo, set()
+    if names:
+        buckets.append((0, hi, names))
+    return buckets
 
 
 def dp_allreduce_(flat: torch.Tensor):

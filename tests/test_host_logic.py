@@ -244,3 +244,25 @@ def test_darknet_backbone_import_roundtrip(tmp_path):
         f.truncate(10_000)
     with pytest.raises(ValueError):
         W.load_darknet_backbone(p)
+
+
+def test_gradient_buckets_tile_the_flat_buffer():
+    """make_buckets (overlapped all-reduce): buckets are contiguous, cover the buffer exactly, never split a layer, come in
+    backward order, and all but the last are at least the requested size."""
+    from object_detector_amd.trainer import make_buckets
+    rng = np.random.default_rng(0)
+    for trial in range(50):
+        sizes = [int(rng.integers(1, 5000)) * 4 for _ in range(int(rng.integers(1, 40)))]
+        layers, off = [], 0
+        for i, n in enumerate(sizes):
+            layers.append((off, off + n, f"l{i}"))
+            off += n
+        min_elems = int(rng.integers(1, 30000))
+        b = make_buckets(layers, off, min_elems)
+        assert b[0][1] == off and b[-1][0] == 0
+        assert all(x[0] == y[1] for x, y in zip(b, b[1:]))                     # descending, contiguous
+        assert all(hi - lo >= min_elems for lo, hi, _ in b[:-1])
+        seen = [n for _lo, _hi, names in b for n in names]
+        assert sorted(seen) == sorted(nm for _, _, nm in layers)               # every layer in exactly one bucket
+        for lo, hi, names in b:
+            assert all(lo <= l0 and h0 <= hi for l0, h0, nm in layers if nm in names)
