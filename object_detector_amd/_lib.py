@@ -175,6 +175,9 @@ def load(path: os.PathLike | None = None):
         raise OdError(
             f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             f"(or `make -C object_detector_amd/csrc`). There is no CPU fallback for this path.")
+    # torch first: libodhip.so must bind to the HIP runtime torch already loaded (the one that owns the tensors whose
+    # pointers cross the C ABI).  Loaded the other way round, a second runtime comes up and sees no device.
+    import torch  # noqa: F401
     lib = C.CDLL(str(p))
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
