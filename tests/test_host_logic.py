@@ -266,3 +266,34 @@ def test_gradient_buckets_tile_the_flat_buffer():
         assert sorted(seen) == sorted(nm for _, _, nm in layers)               # every layer in exactly one bucket
         for lo, hi, names in b:
             assert all(lo <= l0 and h0 <= hi for l0, h0, nm in layers if nm in names)
+
+
+def test_decode_chunk_into_shared_memory(tmp_path):
+    """The decode-worker entry (numpy + PIL only, what OD_DECODE_PROCS workers run) writes resized images at the given
+    offsets of a shared staging block and returns the letterbox scales; it must not import torch."""
+    import subprocess
+    import sys
+    from multiprocessing import shared_memory
+    from PIL import Image
+    from object_detector_amd import imageio
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, 256, (50, 100, 3), dtype=np.uint8)
+    pth = tmp_path / "a.png"
+    Image.fromarray(a).save(pth)
+    H, W = 32, 48
+    nbytes = H * W * 3
+    shm = shared_memory.SharedMemory(create=True, size=3 * nbytes)
+    try:
+        scales = imageio.decode_chunk_into_shm(shm.name, [0, 2 * nbytes], [str(pth), a], (H, W), True)
+        got0 = np.ndarray((H, W, 3), np.uint8, buffer=shm.buf, offset=0).copy()
+        got2 = np.ndarray((H, W, 3), np.uint8, buffer=shm.buf, offset=2 * nbytes).copy()
+        ref, sc = imageio.load_image(a, (H, W), keep_aspect=True, return_scale=True)
+        assert np.array_equal(got0, ref) and np.array_equal(got2, ref)
+        assert scales == [sc, sc] and sc == (1.0, 0.75)
+    finally:
+        imageio._SHM.pop(shm.name, None)
+        shm.close()
+        shm.unlink()
+    r = subprocess.run([sys.executable, "-c", "import sys; import object_detector_amd.imageio; print('torch' in sys.modules)"],
+                       capture_output=True, text=True, cwd=str(pathlib.Path(__file__).resolve().parent.parent))
+    assert r.stdout.strip() == "False", r.stdout + r.stderr
