@@ -13,7 +13,8 @@
  *   - every function returns 0 on success, a negative OD_ERR_* otherwise; od_last_error() gives text
  *   - all tensor arguments are raw DEVICE pointers + explicit dims; `stream` is a hipStream_t passed as void*
  *   - no hidden allocation in any per-step call: the caller owns every buffer, including workspaces whose
- *     size is returned by the matching *_workspace_bytes() query.  od_ctx owns only a 4 KiB zero page.
+ *     size is returned by the matching *_workspace_bytes() query.  od_ctx owns only an 8 KiB zero page and an 8 KiB
+ *     vector of ones (allocated once in od_ctx_create).
  *   - kernels are asynchronous on `stream`; launch errors are mapped to return codes right after launch
  *   - activations are NHWC; f16 storage, f32 accumulation (MFMA v_mfma_f32_16x16x32_f16)
  */
@@ -52,6 +53,15 @@ int od_version(void);
 
 int od_ctx_create(int device, od_ctx** out);
 int od_ctx_destroy(od_ctx* ctx);
+
+/* ABI self-description, so that a foreign-language binding (ctypes, cgo, JNI ...) can verify its mirror of the structs
+ * below against THIS build of the library instead of against a copy of the header: size in bytes of a struct of this
+ * header by name ("od_conv_desc", ...), and the byte offset of one of its fields ("od_conv_desc", "tile_cfg").
+ * -1 = unknown struct / field.  od_struct_fields writes the comma-separated field names of a struct, in declaration
+ * order, into buf (returns the number of fields, -1 unknown struct or buffer too small). */
+long od_sizeof(const char* struct_name);
+long od_offsetof(const char* struct_name, const char* field_name);
+int od_struct_fields(const char* struct_name, char* buf, int buf_bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * K1/K2: fused conv2d forward.  Replaces the Keras Conv2D+BatchNormalization+activation(+Add) layers
@@ -211,6 +221,20 @@ int od_loss_fwd_bwd(od_ctx* ctx, const float* pred, const float* y, float* grad,
  *                    od_conv_desc.transposed = 1 (stride 2); the epilogue's residual input accumulates gradients
  *   backward-weight= od_conv2d_bwd_weight: dw f32 [Cout_pad][Kpad] += dZ^T . shifted(X)   (atomic f32 adds; zero it first)
  * ---------------------------------------------------------------------------------------------- */
+/* backward-data as ONE call (SURVEY.md §8b names it as an export): dx[B, Ho*stride, Wo*stride, Cin] f16
+ * (= dx_accumulate + ..., when dx_accumulate != NULL; it may alias dx) from dz [B,Ho,Wo,Cout] f16 and the w_bwd pack of
+ * od_pack_weights.  A thin wrapper: it fills an od_conv_desc (x = dz, w = w_bwd, identity scale / zero bias owned by the
+ * context, transposed = stride == 2) and runs the SAME implicit-GEMM kernels as od_conv2d_fwd -- there is no separate
+ * backward-data kernel, which is why the trainer calls od_conv2d_fwd directly. */
+int od_conv2d_bwd_data(od_ctx* ctx, const void* dz, const void* w_bwd, const void* dx_accumulate, void* dx, int B, int Ho,
+                       int Wo, int Cin, int Cout, int ksize, int stride, void* stream);
+/* inference-time BatchNorm folding on the device: scale = gamma / sqrt(var + eps), bias = beta - mean*scale,
+ * f32 [C], bit-identical to the numpy f32 expression the loader (object_detector_amd/weights.py fold_bn) evaluates on the
+ * host -- the loader folds once on the host at load time, this export is for callers that keep the statistics on the
+ * device (e.g. evaluating during training).  The training-mode forward/backward of BatchNorm are od_bn_stats +
+ * od_scale_act and od_bn_bwd below (§8b's od_bn_train_fwd / od_bn_train_bwd). */
+int od_bn_fold(od_ctx* ctx, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+               float* scale, float* bias, int C, void* stream);
 size_t od_bn_workspace_bytes(long long M, int C);
 /* batch statistics of z [M,C] -> mean, rstd, and the fused (scale, shift) = (gamma*rstd, beta - mean*scale);
  * run_mean/run_var (may be NULL) updated with `momentum` */

@@ -21,6 +21,7 @@ ACT_ENUM = {None: OD_ACT_LINEAR, "linear": OD_ACT_LINEAR, "leaky": OD_ACT_LEAKY,
 
 
 class ConvDesc(C.Structure):
+    C_NAME = "od_conv_desc"  # the struct of include/odhip.h this mirrors (layout checked by tests/test_host_logic.py)
     _fields_ = [
         ("x", C.c_void_p), ("w", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p),
         ("res", C.c_void_p), ("out", C.c_void_p),
@@ -34,6 +35,7 @@ class ConvDesc(C.Structure):
 
 
 class AugParams(C.Structure):
+    C_NAME = "od_aug_params"  # the struct of include/odhip.h this mirrors (layout checked by tests/test_host_logic.py)
     _fields_ = [("src_offset", C.c_int64), ("src_h", C.c_int32), ("src_w", C.c_int32),
                 ("crop_x1", C.c_float), ("crop_y1", C.c_float), ("crop_x2", C.c_float), ("crop_y2", C.c_float),
                 ("flip", C.c_int32), ("brightness", C.c_float), ("contrast", C.c_float), ("saturation", C.c_float),
@@ -41,6 +43,7 @@ class AugParams(C.Structure):
 
 
 class BneckDesc(C.Structure):
+    C_NAME = "od_bneck_desc"  # the struct of include/odhip.h this mirrors (layout checked by tests/test_host_logic.py)
     _fields_ = [
         ("x", C.c_void_p), ("w1", C.c_void_p), ("scale1", C.c_void_p), ("bias1", C.c_void_p),
         ("w3", C.c_void_p), ("scale3", C.c_void_p), ("bias3", C.c_void_p), ("out", C.c_void_p),
@@ -50,6 +53,7 @@ class BneckDesc(C.Structure):
 
 
 class StemDesc(C.Structure):
+    C_NAME = "od_stem_desc"  # the struct of include/odhip.h this mirrors (layout checked by tests/test_host_logic.py)
     _fields_ = [
         ("x", C.c_void_p), ("w0", C.c_void_p), ("scale0", C.c_void_p), ("bias0", C.c_void_p),
         ("w3", C.c_void_p), ("scale3", C.c_void_p), ("bias3", C.c_void_p), ("out", C.c_void_p),
@@ -58,21 +62,28 @@ class StemDesc(C.Structure):
 
 
 class SgdSeg(C.Structure):
+    C_NAME = "od_sgd_seg"  # the struct of include/odhip.h this mirrors (layout checked by tests/test_host_logic.py)
     _fields_ = [("offset", C.c_int64), ("count", C.c_int64), ("lr", C.c_float), ("weight_decay", C.c_float)]
 
 
 class WgradRed(C.Structure):
+    C_NAME = "od_wgrad_red"  # the struct of include/odhip.h this mirrors (layout checked by tests/test_host_logic.py)
     _fields_ = [("dw_offset", C.c_int64), ("count", C.c_int64), ("slabs", C.c_void_p), ("nslabs", C.c_int32),
                 ("pad_", C.c_int32)]
 
 
 class PackLayer(C.Structure):
+    C_NAME = "od_pack_layer"  # the struct of include/odhip.h this mirrors (layout checked by tests/test_host_logic.py)
     _fields_ = [("w_offset", C.c_int64), ("w_fwd", C.c_void_p), ("w_bwd", C.c_void_p),
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("ksize", C.c_int32), ("pad_", C.c_int32)]
 
 
 class PlanOp(C.Structure):
+    C_NAME = "od_plan_op"  # the struct of include/odhip.h this mirrors (layout checked by tests/test_host_logic.py)
     _fields_ = [("kind", C.c_int32), ("pad_", C.c_int32), ("conv", ConvDesc), ("bneck", BneckDesc), ("stem", StemDesc)]
+
+
+STRUCTS = (ConvDesc, AugParams, BneckDesc, StemDesc, SgdSeg, WgradRed, PackLayer, PlanOp)
 
 
 class OdError(RuntimeError):
@@ -87,6 +98,9 @@ _PROTOS = {
     "od_version": (C.c_int, []),
     "od_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "od_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "od_sizeof": (C.c_long, [C.c_char_p]),
+    "od_offsetof": (C.c_long, [C.c_char_p, C.c_char_p]),
+    "od_struct_fields": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
     "od_conv_weight_dims": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "od_conv_num_tile_cfgs": (C.c_int, []),
     "od_conv2d_fwd": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_void_p]),
@@ -116,6 +130,10 @@ _PROTOS = {
     "od_loss_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                   C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float,
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
+    "od_conv2d_bwd_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "od_bn_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                             C.c_int, C.c_void_p]),
     "od_bn_workspace_bytes": (C.c_size_t, [C.c_longlong, C.c_int]),
     "od_bn_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,

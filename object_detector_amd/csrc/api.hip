@@ -1,4 +1,5 @@
 // Context, error reporting and the native forward plan of libodhip.so.
+#include <stddef.h>
 #include <string.h>
 
 #include <string>
@@ -24,6 +25,7 @@ extern "C" int od_ctx_create(int device, od_ctx** out) {
   od_ctx* c = new od_ctx();
   c->device = device;
   c->zero_page = nullptr;
+  c->ones = nullptr;
   hipDeviceProp_t prop;
   OD_CHECK_HIP(hipGetDeviceProperties(&prop, device));
   c->num_cu = prop.multiProcessorCount;
@@ -33,15 +35,118 @@ extern "C" int od_ctx_create(int device, od_ctx** out) {
     delete c;
     return OD_ERR_INVALID;
   }
-  OD_CHECK_HIP(hipMalloc(&c->zero_page, 4096));
-  OD_CHECK_HIP(hipMemset(c->zero_page, 0, 4096));
+  OD_CHECK_HIP(hipMalloc(&c->zero_page, 8192));
+  OD_CHECK_HIP(hipMemset(c->zero_page, 0, 8192));
+  {
+    std::vector<float> one(2048, 1.0f);
+    OD_CHECK_HIP(hipMalloc((void**)&c->ones, 8192));
+    OD_CHECK_HIP(hipMemcpy(c->ones, one.data(), 8192, hipMemcpyHostToDevice));
+  }
   *out = c;
+  return OD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ABI self-description (od_sizeof / od_offsetof / od_struct_fields)
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct FieldInfo {
+  const char* name;
+  long offset;
+};
+struct StructInfo {
+  const char* name;
+  long size;
+  std::vector<FieldInfo> fields;
+};
+#define OD_F(S, f) {#f, (long)offsetof(S, f)}
+const std::vector<StructInfo>& od_struct_table() {
+  static const std::vector<StructInfo> t = {
+      {"od_conv_desc", sizeof(od_conv_desc),
+       {OD_F(od_conv_desc, x), OD_F(od_conv_desc, w), OD_F(od_conv_desc, scale), OD_F(od_conv_desc, bias),
+        OD_F(od_conv_desc, res), OD_F(od_conv_desc, out), OD_F(od_conv_desc, B), OD_F(od_conv_desc, H),
+        OD_F(od_conv_desc, W), OD_F(od_conv_desc, Cin), OD_F(od_conv_desc, Cout), OD_F(od_conv_desc, ksize),
+        OD_F(od_conv_desc, stride), OD_F(od_conv_desc, act), OD_F(od_conv_desc, alpha), OD_F(od_conv_desc, res_mode),
+        OD_F(od_conv_desc, out_dtype), OD_F(od_conv_desc, out_batch_stride), OD_F(od_conv_desc, out_pix_stride),
+        OD_F(od_conv_desc, tile_cfg), OD_F(od_conv_desc, transposed), OD_F(od_conv_desc, splitk),
+        OD_F(od_conv_desc, splitk_workspace), OD_F(od_conv_desc, splitk_workspace_bytes)}},
+      {"od_bneck_desc", sizeof(od_bneck_desc),
+       {OD_F(od_bneck_desc, x), OD_F(od_bneck_desc, w1), OD_F(od_bneck_desc, scale1), OD_F(od_bneck_desc, bias1),
+        OD_F(od_bneck_desc, w3), OD_F(od_bneck_desc, scale3), OD_F(od_bneck_desc, bias3), OD_F(od_bneck_desc, out),
+        OD_F(od_bneck_desc, B), OD_F(od_bneck_desc, H), OD_F(od_bneck_desc, W), OD_F(od_bneck_desc, C),
+        OD_F(od_bneck_desc, act), OD_F(od_bneck_desc, alpha)}},
+      {"od_stem_desc", sizeof(od_stem_desc),
+       {OD_F(od_stem_desc, x), OD_F(od_stem_desc, w0), OD_F(od_stem_desc, scale0), OD_F(od_stem_desc, bias0),
+        OD_F(od_stem_desc, w3), OD_F(od_stem_desc, scale3), OD_F(od_stem_desc, bias3), OD_F(od_stem_desc, out),
+        OD_F(od_stem_desc, B), OD_F(od_stem_desc, H), OD_F(od_stem_desc, W), OD_F(od_stem_desc, act),
+        OD_F(od_stem_desc, alpha)}},
+      {"od_wgrad_red", sizeof(od_wgrad_red),
+       {OD_F(od_wgrad_red, dw_offset), OD_F(od_wgrad_red, count), OD_F(od_wgrad_red, slabs), OD_F(od_wgrad_red, nslabs),
+        OD_F(od_wgrad_red, pad_)}},
+      {"od_sgd_seg", sizeof(od_sgd_seg),
+       {OD_F(od_sgd_seg, offset), OD_F(od_sgd_seg, count), OD_F(od_sgd_seg, lr), OD_F(od_sgd_seg, weight_decay)}},
+      {"od_pack_layer", sizeof(od_pack_layer),
+       {OD_F(od_pack_layer, w_offset), OD_F(od_pack_layer, w_fwd), OD_F(od_pack_layer, w_bwd), OD_F(od_pack_layer, Cout),
+        OD_F(od_pack_layer, Cin), OD_F(od_pack_layer, ksize), OD_F(od_pack_layer, pad_)}},
+      {"od_aug_params", sizeof(od_aug_params),
+       {OD_F(od_aug_params, src_offset), OD_F(od_aug_params, src_h), OD_F(od_aug_params, src_w),
+        OD_F(od_aug_params, crop_x1), OD_F(od_aug_params, crop_y1), OD_F(od_aug_params, crop_x2),
+        OD_F(od_aug_params, crop_y2), OD_F(od_aug_params, flip), OD_F(od_aug_params, brightness),
+        OD_F(od_aug_params, contrast), OD_F(od_aug_params, saturation), OD_F(od_aug_params, n_erase),
+        OD_F(od_aug_params, erase), OD_F(od_aug_params, erase_rgb)}},
+      {"od_plan_op", sizeof(od_plan_op),
+       {OD_F(od_plan_op, kind), OD_F(od_plan_op, pad_), OD_F(od_plan_op, conv), OD_F(od_plan_op, bneck),
+        OD_F(od_plan_op, stem)}},
+  };
+  return t;
+}
+#undef OD_F
+const StructInfo* od_find_struct(const char* name) {
+  if (!name) return nullptr;
+  for (const StructInfo& s : od_struct_table())
+    if (strcmp(s.name, name) == 0) return &s;
+  return nullptr;
+}
+}  // namespace
+
+extern "C" long od_sizeof(const char* struct_name) {
+  const StructInfo* s = od_find_struct(struct_name);
+  return s ? s->size : -1;
+}
+
+extern "C" long od_offsetof(const char* struct_name, const char* field_name) {
+  const StructInfo* s = od_find_struct(struct_name);
+  if (!s || !field_name) return -1;
+  for (const FieldInfo& f : s->fields)
+    if (strcmp(f.name, field_name) == 0) return f.offset;
+  return -1;
+}
+
+extern "C" int od_struct_fields(const char* struct_name, char* buf, int buf_bytes) {
+  const StructInfo* s = od_find_struct(struct_name);
+  if (!s || !buf) return -1;
+  std::string out;
+  for (const FieldInfo& f : s->fields) {
+    if (!out.empty()) out += ",";
+    out += f.name;
+  }
+  if ((int)out.size() + 1 > buf_bytes) return -1;
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return (int)s->fields.size();
+}
+
+int od_ensure_lds(od_ctx* ctx, const void* fn, size_t lds) {
+  auto it = ctx->lds_attr.find(fn);
+  if (it != ctx->lds_attr.end() && it->second >= lds) return OD_OK;
+  OD_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  ctx->lds_attr[fn] = lds;
   return OD_OK;
 }
 
 extern "C" int od_ctx_destroy(od_ctx* ctx) {
   if (!ctx) return OD_OK;
   if (ctx->zero_page) (void)hipFree(ctx->zero_page);
+  if (ctx->ones) (void)hipFree(ctx->ones);
   delete ctx;
   return OD_OK;
 }

@@ -5,13 +5,22 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <unordered_map>
+
 #include "../../include/odhip.h"
 
 struct od_ctx {
   int device;
-  void* zero_page;  // 4 KiB of zeros: source for padded / out-of-range lanes of LDS-DMA gathers
+  void* zero_page;  // 8 KiB of zeros: source for padded / out-of-range lanes of LDS-DMA gathers; a zero bias vector
+  float* ones;      // 2048 x 1.0f: identity scale vector of od_conv2d_bwd_data
   int num_cu;
+  // largest dynamic-LDS size already granted to each kernel ON THIS DEVICE (hipFuncAttributeMaxDynamicSharedMemorySize is
+  // per device, and one process may hold a context per GPU): see od_ensure_lds
+  std::unordered_map<const void*, size_t> lds_attr;
 };
+
+// Raise the kernel's dynamic-LDS limit to `lds` bytes on ctx's device unless that was already done through this context.
+int od_ensure_lds(od_ctx* ctx, const void* fn, size_t lds);
 
 void od_set_error(const char* fmt, ...);
 

@@ -467,12 +467,7 @@ extern "C" int od_bottleneck_fwd(od_ctx* ctx, const od_bneck_desc* d, void* stre
   const void* fn = d->C == 64 ? (dbg == 32 ? (const void*)&od_bneck<64, 1> : (const void*)&od_bneck<64>)
                               : (const void*)&od_bneck<128>;
   const int lds = d->C == 64 ? BneckCfg<64>::LDS_BYTES : BneckCfg<128>::LDS_BYTES;
-  static bool attr_done[2] = {false, false};
-  const int slot = d->C == 64 ? 0 : 1;
-  if (!attr_done[slot]) {
-    OD_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_done[slot] = true;
-  }
+  if (int rc = od_ensure_lds(ctx, fn, (size_t)lds)) return rc;
   int ntiles = d->B * p.tiles_x * p.tiles_y;
   // C = 64: persistent workgroups (one per CU) walk the tiles; C = 128: one workgroup per tile
   const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;

@@ -614,11 +614,7 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
     p.ntiles = od_ceil_div(d->Cout, ki.BN);
     if (kernel_name) *kernel_name = ki.name;
     if (dry_run) return OD_OK;
-    static size_t pw_attr = 0;
-    if (lds > pw_attr) {
-      OD_CHECK_HIP(hipFuncSetAttribute(ki.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      pw_attr = lds;
-    }
+    if (int rc = od_ensure_lds(ctx, ki.fn, lds)) return rc;
     void* wargs[] = {&p, &np, &ntt};
     OD_CHECK_HIP(hipLaunchKernel(ki.fn, dim3(grid), dim3(ki.threads), wargs, lds, stream));
     return OD_OK;
@@ -640,12 +636,7 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
     p.ntiles = od_ceil_div(d->Cout, ki.BN);
     if (kernel_name) *kernel_name = ki.name;
     if (dry_run) return OD_OK;
-    static size_t win_attr[16] = {};
-    const int wi = cfg - kNumCfgs;
-    if (lds > win_attr[wi]) {
-      OD_CHECK_HIP(hipFuncSetAttribute(ki.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      win_attr[wi] = lds;
-    }
+    if (int rc = od_ensure_lds(ctx, ki.fn, lds)) return rc;
     int np = (ki.BM + 2 * d->W + 2 + 15) / 16;
     void* wargs[] = {&p, &np};
     OD_CHECK_HIP(hipLaunchKernel(ki.fn, dim3(p.mtiles * p.ntiles), dim3(ki.threads), wargs, lds, stream));
@@ -710,12 +701,7 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
   if (kernel_name) *kernel_name = use_e8 ? e8.name : (variant == 0 ? tc.name1 : (variant == 1 ? tc.name3 : tc.name3g));
   if (dry_run) return OD_OK;
 
-  static bool attr_done[kNumCfgs + 16][3] = {};
-  const int attr_slot = use_e8 ? kNumCfgs + (cfg - cfg_e8) : cfg;
-  if (!attr_done[attr_slot][variant]) {
-    OD_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tc.lds));
-    attr_done[attr_slot][variant] = true;
-  }
+  if (int rc = od_ensure_lds(ctx, fn, tc.lds)) return rc;
   void* args[] = {&p};
   // the 8-wave kernel's epilogue needs no LDS unless it writes split-K slabs: ask only for the two K-tile buffers then
   // (128 KiB), which leaves room on the CU for a small workgroup of another stream

@@ -313,11 +313,7 @@ extern "C" int od_stem_fwd(od_ctx* ctx, const od_stem_desc* d, void* stream) {
   int ntiles = d->B * p.tiles_x * p.tiles_y;
   const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
   const int grid = ntiles < cus ? ntiles : cus;
-  static bool attr_done = false;
-  if (!attr_done) {
-    OD_CHECK_HIP(hipFuncSetAttribute((const void*)&od_stem, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS));
-    attr_done = true;
-  }
+  if (int rc = od_ensure_lds(ctx, (const void*)&od_stem, (size_t)S_LDS)) return rc;
   void* args[] = {&p, &ntiles};
   OD_CHECK_HIP(hipLaunchKernel((const void*)&od_stem, dim3((unsigned)grid), dim3(512), args, (size_t)S_LDS, (hipStream_t)stream));
   return OD_OK;

@@ -182,11 +182,7 @@ extern "C" int od_loss_fwd_bwd(od_ctx* ctx, const float* pred, const float* y, f
   hipLaunchKernelGGL(od_loss_count, dim3(cb), dim3(256), 0, s, y, R, NC + 6, npos);
   OD_CHECK_LAUNCH();
   const size_t lds = (size_t)2 * LROWS * (NC + 6) * sizeof(float);
-  static size_t attr_lds = 0;
-  if (lds > attr_lds) {
-    OD_CHECK_HIP(hipFuncSetAttribute((const void*)&od_loss_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_lds = lds;
-  }
+  if (int rc = od_ensure_lds(ctx, (const void*)&od_loss_rows, lds)) return rc;
   hipLaunchKernelGGL(od_loss_rows, dim3(nblocks), dim3(256), lds, s, pred, y, grad, R, NC, focal_alpha, focal_gamma,
                      box_mode, w_obj, w_cls, w_box, npos, partials);
   OD_CHECK_LAUNCH();

@@ -223,11 +223,7 @@ extern "C" int od_nms(od_ctx* ctx, const float* boxes, const uint64_t* keys, con
                      strict, mask);
   OD_CHECK_LAUNCH();
   const size_t scan_lds = (size_t)KP * W * 8 + 16 * 8;
-  static size_t scan_attr = 0;
-  if (scan_lds > scan_attr) {
-    OD_CHECK_HIP(hipFuncSetAttribute((const void*)&od_nms_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
-    scan_attr = scan_lds;
-  }
+  if (int rc = od_ensure_lds(ctx, (const void*)&od_nms_scan, scan_lds)) return rc;
   hipLaunchKernelGGL(od_nms_scan, dim3(B), dim3(256), scan_lds, s, mask, skeys, counts, KP, W, max_det, keep_flat,
                      keep_count);
   OD_CHECK_LAUNCH();

@@ -115,11 +115,7 @@ extern "C" int od_head_postprocess(od_ctx* ctx, const float* pred, const float* 
   OD_REQUIRE(B > 0 && P > 0 && NC > 0 && NC <= 90, "od_head_postprocess: bad dims (NC <= 90)");
   const long long rows = (long long)B * P;
   const size_t lds = (size_t)PP_ROWS * (NC + 6 + NC) * sizeof(float);
-  static size_t attr_lds = 0;
-  if (lds > attr_lds) {
-    OD_CHECK_HIP(hipFuncSetAttribute((const void*)&od_head_post, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_lds = lds;
-  }
+  if (int rc = od_ensure_lds(ctx, (const void*)&od_head_post, lds)) return rc;
   const unsigned grid = (unsigned)((rows + PP_ROWS - 1) / PP_ROWS);
   hipLaunchKernelGGL(od_head_post, dim3(grid), dim3(256), lds, (hipStream_t)stream, pred, priors, conf, boxes, rows, P,
                      NC, loc_scale, clip);

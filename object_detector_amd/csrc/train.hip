@@ -12,6 +12,8 @@
 //
 // reference: the Keras BatchNormalization / activation / optimizer machinery behind the (unseen) `fit` of
 // tk.dl.od.ObjectDetector; specified here by docs/MODEL.md:19-21,84-90.
+#include <string.h>
+
 #include "common.h"
 
 namespace {
@@ -504,6 +506,54 @@ unsigned grid_for(long long nvec) {
 }
 
 }  // namespace
+
+__global__ void od_bn_fold_k(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                             const float* __restrict__ var, float eps, float* __restrict__ scale, float* __restrict__ bias,
+                             int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(var[c] + eps);  // correctly rounded divide / sqrt, no contraction: = numpy f32
+  scale[c] = sc;
+  bias[c] = beta[c] - mean[c] * sc;
+}
+
+extern "C" int od_bn_fold(od_ctx* ctx, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                          float* scale, float* bias, int C, void* stream) {
+  OD_REQUIRE(ctx && gamma && beta && mean && var && scale && bias, "od_bn_fold: null argument");
+  OD_REQUIRE(C > 0, "od_bn_fold: C <= 0");
+  hipLaunchKernelGGL(od_bn_fold_k, dim3(od_ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, eps,
+                     scale, bias, C);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
+extern "C" int od_conv2d_bwd_data(od_ctx* ctx, const void* dz, const void* w_bwd, const void* dx_accumulate, void* dx, int B,
+                                  int Ho, int Wo, int Cin, int Cout, int ksize, int stride, void* stream) {
+  OD_REQUIRE(ctx && dz && w_bwd && dx, "od_conv2d_bwd_data: null argument");
+  OD_REQUIRE(Cin > 0 && Cin <= 2048, "od_conv2d_bwd_data: Cin out of range (1..2048)");
+  od_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.x = dz;
+  d.w = w_bwd;
+  d.scale = ctx->ones;
+  d.bias = (const float*)ctx->zero_page;
+  d.res = dx_accumulate;
+  d.res_mode = dx_accumulate ? OD_RES_SAME : OD_RES_NONE;
+  d.out = dx;
+  d.B = B;
+  d.H = Ho;
+  d.W = Wo;
+  d.Cin = Cout;  // the backward-data conv contracts over the forward conv's output channels
+  d.Cout = Cin;
+  d.ksize = ksize;
+  d.stride = stride;
+  d.act = OD_ACT_LINEAR;
+  d.out_dtype = OD_DT_F16;
+  d.tile_cfg = -1;
+  d.transposed = stride == 2;
+  d.splitk = 1;
+  return od_conv2d_fwd_impl(ctx, &d, (hipStream_t)stream, nullptr, false);
+}
 
 extern "C" size_t od_bn_workspace_bytes(long long M, int C) {
   if (M <= 0 || C <= 0 || C % 8) return 0;

@@ -169,7 +169,10 @@ class Net:
                                  bytes=float(self.B * h * w * cin * 2 + m * cout * osz + cout * k * k * cin * 2
                                              + (m * cout * 2 if res_mode == _lib.OD_RES_SAME else 0)
                                              + (m * cout // 2 if res_mode == _lib.OD_RES_UP2 else 0)),
-                                 shape=(m, cout, k * k * cin)))
+                                 shape=(m, cout, k * k * cin),
+                                 # the op's tensors, for per-layer parity checks (tests/test_gpu_fullsize.py)
+                                 kind="conv", x=x, res=res, res_mode=res_mode, out=None if isinstance(out, int) else out,
+                                 stride=stride, ksize=k, act=act, out_f32=out_f32))
         return out, ho, wo
 
     def _bneck(self, name, x, h, w, ch, act):
@@ -190,7 +193,7 @@ class Net:
         m = self.B * h * w
         self.op_info.append(dict(name=name, flops=2.0 * m * (ch * (ch // 2) + 9 * (ch // 2) * ch),
                                  bytes=float(2 * m * ch * 2 + (ch * ch // 2 + 9 * ch * ch // 2) * 2),
-                                 shape=(m, ch, 10 * (ch // 2))))
+                                 shape=(m, ch, 10 * (ch // 2)), kind="bneck", x=x, out=out, act=act))
         return out
 
     def _build(self, bact, hact):
@@ -214,7 +217,8 @@ class Net:
             self.ops.append(op)
             m1 = B * (H // 2) * (Wd // 2)
             self.op_info.append(dict(name="b.stem", flops=2.0 * B * H * Wd * 32 * 27 + 2.0 * m1 * 64 * 288,
-                                     bytes=float(B * H * Wd * 3 + m1 * 64 * 2), shape=(m1, 64, 288 + 27)))
+                                     bytes=float(B * H * Wd * 3 + m1 * 64 * 2), shape=(m1, 64, 288 + 27),
+                                     kind="stem", x=self.input, out=x, act=bact))
         else:
             # first layer (uint8 in)
             wt, sc, bi = self._dev["b.conv0"]
@@ -230,7 +234,8 @@ class Net:
             op.conv = d
             self.ops.append(op)
             self.op_info.append(dict(name="b.conv0", flops=2.0 * B * H * Wd * 32 * 27,
-                                     bytes=float(B * H * Wd * (3 + 64)), shape=(B * H * Wd, 32, 27)))
+                                     bytes=float(B * H * Wd * (3 + 64)), shape=(B * H * Wd, 32, 27),
+                                     kind="first", x=self.input, out=x, act=bact))
         h, w, cin = H, Wd, 32
         taps = []
         for si, (n, ch) in enumerate(W.STAGES, start=1):
@@ -267,6 +272,7 @@ class Net:
             out_ptr = self.pred.data_ptr() + off * self.C * 4
             self._conv("h.out", t, h, w, nc, cout, 3, 1, None, out=out_ptr, out_f32=True,
                        obs=self.P * self.C, ops=cout)
+            self.op_info[-1]["pred_rows"] = (off, h * w * W.NUM_PRIORS)
             off += h * w * W.NUM_PRIORS
         assert off == self.P
 

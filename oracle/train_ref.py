@@ -12,16 +12,28 @@ from . import loss as oloss
 from .network import BN_EPS, NUM_PRIORS, STAGES
 
 
-def _act(a, act):
+def _act(a, act, mask=None):
     if act is None:
         return a
     if act[0] == "leaky":
+        if mask is not None:  # slope chosen by a given sign pattern instead of a's own sign (see TorchDetector.slope_masks)
+            return a * torch.where(mask, torch.ones((), dtype=a.dtype), torch.full((), act[1], dtype=a.dtype))
         return F.leaky_relu(a, act[1])
     return F.elu(a, act[1])
 
 
 class TorchDetector:
-    def __init__(self, params, backbone_act=("leaky", 0.1), head_act=("elu", 1.0), dtype=torch.float64):
+    """slope_masks: {layer name: bool array [B,Ho,Wo,Cout]} = which side of the LeakyReLU kink every unit of that layer
+    is to be treated as being on (True = positive).  A unit whose pre-activation is within the f16 pipeline's rounding
+    noise of 0 lands on the other side of the kink on the device than here; its forward value changes by <= 0.9*|a| (tiny)
+    but its slope by 10x.  Passing the device's pattern makes this oracle differentiate the SAME piecewise-linear
+    function the device ran, so the remaining gradient error is arithmetic only; `flips` counts the units that moved."""
+
+    def __init__(self, params, backbone_act=("leaky", 0.1), head_act=("elu", 1.0), dtype=torch.float64, slope_masks=None):
+        self.slope_masks = slope_masks or {}
+        self.flips, self.units = {}, {}
+        self.record_patterns = False  # True: forward() keeps this run's own sign pattern per leaky layer in .patterns
+        self.patterns = {}
         self.p = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=not (k.endswith(".mean") or k.endswith(".var")))
                   for k, v in params.items()}
         self.bact, self.hact, self.dtype = backbone_act, head_act, dtype
@@ -37,7 +49,16 @@ class TorchDetector:
             z = z * self.p[name + ".gamma"].view(1, -1, 1, 1) + self.p[name + ".beta"].view(1, -1, 1, 1)
         else:
             z = z + self.p[name + ".bias"].view(1, -1, 1, 1)
-        y = _act(z, act)
+        mask = self.slope_masks.get(name)
+        if mask is not None and act is not None and act[0] == "leaky":
+            mask = torch.from_numpy(np.ascontiguousarray(mask)).permute(0, 3, 1, 2)
+            self.flips[name] = int(((z.detach() > 0) != mask).sum())
+            self.units[name] = mask.numel()
+        else:
+            mask = None
+        if self.record_patterns and act is not None and act[0] == "leaky":
+            self.patterns[name] = (z.detach() > 0).permute(0, 2, 3, 1).contiguous().numpy()
+        y = _act(z, act, mask)
         if res is not None:
             y = y + (F.interpolate(res, scale_factor=2, mode="nearest") if up2 else res)
         return y

@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# Adapted from ak110/object_detector check_generator.py (MIT): the same argparse flags and tk.* call sequence.
 """Visual check of the data generator / augmentation (equivalent of the reference's check_generator.py)."""
 import argparse
 import pathlib

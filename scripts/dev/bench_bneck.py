@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 from object_detector_amd import _lib  # noqa: E402
 from object_detector_amd.net import Context, pack_conv_weight, pad_vec  # noqa: E402
 

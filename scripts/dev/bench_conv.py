@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of od_conv2d_fwd tile configurations on the Darknet53 layer shapes (MI355X tuning tool).
-usage: python scripts/bench_conv.py [--batch 32] [--size 320] [--shapes big|net|all] [--cfgs 0,1,2,3]"""
+usage: python scripts/dev/bench_conv.py [--batch 32] [--size 320] [--shapes big|net|all] [--cfgs 0,1,2,3]"""
 import argparse
 import ctypes as C
 import pathlib
@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 from object_detector_amd import _lib  # noqa: E402
 from object_detector_amd.net import Context, pack_conv_weight  # noqa: E402
 

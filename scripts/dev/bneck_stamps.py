@@ -2,7 +2,7 @@
 """s_memtime stamps of od_bneck<64> (OD_CONV_DEBUG=32 build): 6th tile of workgroup 0, waves 0 and 5."""
 import ctypes as C, os, pathlib, subprocess, sys
 os.environ["OD_CONV_DEBUG"] = "32"
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent))
 import torch
 sys.argv = [sys.argv[0], "--only", "64", "--reps", "3"]

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 import sys, pathlib
 import numpy as np, torch
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent / "tests"))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent / "tests"))
 from object_detector_amd import ops
 import test_gpu_bneck as T
 case = eval(sys.argv[1])

@@ -2,8 +2,8 @@
 """Debug helper: run one conv parity case and print where it differs from the oracle."""
 import sys, pathlib
 import numpy as np, torch
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent / "tests"))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent / "tests"))
 from object_detector_amd import ops
 import test_gpu_conv as T
 

@@ -1,6 +1,6 @@
 import sys, pathlib
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent / "tests"))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent / "tests"))
 import numpy as np, torch
 from test_gpu_trainer import _setup
 from object_detector_amd.trainer import Trainer

@@ -6,7 +6,7 @@ import pathlib
 import sys
 
 os.environ["OD_CONV_DEBUG"] = "32"
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent))
 import torch  # noqa: E402
 import bench_conv  # noqa: E402

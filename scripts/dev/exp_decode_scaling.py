@@ -2,7 +2,7 @@
 """Host-only: JPEG decode + resize throughput of a thread pool vs a process pool (is the GIL or the box's CPU share the limit?)."""
 import os, sys, time, tempfile, pathlib
 import numpy as np
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 from concurrent.futures import ThreadPoolExecutor, ProcessPoolExecutor
 from PIL import Image
 

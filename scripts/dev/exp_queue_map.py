@@ -2,7 +2,7 @@
 """Does the in-flight speedup survive other streams having been created first?  (HIP maps streams onto a few hardware queues.)"""
 import sys, pathlib, time
 import torch
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 from object_detector_amd.detector import ObjectDetector
 
 ndummy = int(sys.argv[1]) if len(sys.argv) > 1 else 0

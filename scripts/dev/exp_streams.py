@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Experiment: one batch-B detector vs S concurrent batch-B/S detectors on S HIP streams (kernel tails / ramps of one
-sub-batch overlap the main phases of the others).  usage: python scripts/exp_streams.py [--batch 32] [--size 320]"""
+sub-batch overlap the main phases of the others).  usage: python scripts/dev/exp_streams.py [--batch 32] [--size 320]"""
 import argparse
 import pathlib
 import sys
@@ -8,7 +8,7 @@ import time
 
 import torch
 
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 from object_detector_amd.detector import ObjectDetector  # noqa: E402
 
 

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
-ARGS="$R/scripts/bench_bneck.py --only $1 --reps 10"
+ARGS="$R/scripts/dev/bench_bneck.py --only $1 --reps 10"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmcb_$2_a -- python3 $ARGS > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM --output-format csv -d $R/gpurun_out/pmcb_$2_b -- python3 $ARGS > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS --output-format csv -d $R/gpurun_out/pmcb_$2_c -- python3 $ARGS > /dev/null 2>&1

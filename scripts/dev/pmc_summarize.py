@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc CSV output dirs: per kernel, mean duration (us) and mean of every counter per dispatch.
-usage: python scripts/pmc_summarize.py <dir> [<dir> ...] [--match substr]"""
+usage: python scripts/dev/pmc_summarize.py <dir> [<dir> ...] [--match substr]"""
 import collections
 import csv
 import glob

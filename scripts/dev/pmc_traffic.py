@@ -2,7 +2,7 @@
 """Per-kernel HBM-side traffic from the two PMC passes of scripts/pmc_bench.sh (FETCH_SIZE / WRITE_SIZE collected in
 separate rocprofv3 --pmc runs, as the MI355X guide prescribes), with the gfx950 correction: FETCH_SIZE counts 128-byte
 requests as 64 bytes, so bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
-usage: python scripts/pmc_traffic.py gpurun_out/pmcb_fetch gpurun_out/pmcb_write > profiles/r01/pmc_traffic.json"""
+usage: python scripts/dev/pmc_traffic.py gpurun_out/pmcb_fetch gpurun_out/pmcb_write > profiles/r01/pmc_traffic.json"""
 import collections
 import csv
 import glob

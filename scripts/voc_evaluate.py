@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# Adapted from ak110/object_detector voc_evaluate.py (MIT): the same argparse flags and tk.* call sequence.
 """Per-class precision / recall / F at conf 0.6 + plots of the first 64 predictions (equivalent of the reference's
 voc_evaluate.py entry point)."""
 import argparse

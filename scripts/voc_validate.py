@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# Adapted from ak110/object_detector voc_validate.py (MIT): the same argparse flags and tk.* call sequence.
 """VOC07-test mAP of the detector (this build's equivalent of the reference's voc_validate.py entry point;
 same flags plus --weights / --synthetic N, because VOC data and trained weights are not available offline)."""
 import argparse

@@ -204,3 +204,38 @@ def test_conv_rejects_bad_args(cuda):
     x = torch.zeros((1, 4, 4, 6), dtype=torch.float16, device=cuda)  # Cin % 8 != 0
     with pytest.raises(_lib.OdError):
         ops.conv2d(x, np.zeros((8, 3, 3, 6), np.float32), np.ones(8), np.zeros(8))
+
+
+def test_integration_md_stub_runs_a_conv(cuda):
+    """INTEGRATION.md §2, both code blocks executed VERBATIM (only the library path is made absolute): the stub a pytoolkit
+    maintainer would add must drive one fused conv + BN + LeakyReLU correctly through the C ABI."""
+    import pathlib
+    import re
+    from object_detector_amd import _lib
+    from object_detector_amd.net import pack_conv_weight
+    md = (pathlib.Path(__file__).resolve().parent.parent / "INTEGRATION.md").read_text()
+    blocks = re.findall(r"```python\n(.*?)```", md, flags=re.S)
+    assert len(blocks) >= 2
+    ns = {}
+    exec(blocks[0].replace('C.CDLL("libodhip.so")', f'C.CDLL({str(_lib.LIB_PATH)!r})'), ns)
+    exec(blocks[1], ns)
+    B, H, Wd, Cin, Cout, k, stride = 2, 16, 16, 64, 128, 3, 2
+    rng = np.random.default_rng(11)
+    x = rng.normal(0, 1, (B, H, Wd, Cin)).astype(np.float16)
+    w = (rng.normal(0, 1, (Cout, k, k, Cin)) * np.sqrt(2.0 / (k * k * Cin))).astype(np.float16)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    bias = rng.normal(0, 0.1, Cout).astype(np.float32)
+    cp, kp = ns["C"].c_int(), ns["C"].c_int()
+    ns["check"](ns["lib"].od_conv_weight_dims(Cout, Cin, k, ns["C"].byref(cp), ns["C"].byref(kp)))
+    wp = pack_conv_weight(w.astype(np.float32))
+    assert wp.shape == (cp.value, kp.value)
+    pad = lambda v: np.concatenate([v, np.zeros(cp.value - len(v), np.float32)])
+    xd, wd = torch.from_numpy(x).to(cuda), torch.from_numpy(wp).to(cuda)
+    sd, bd = torch.from_numpy(pad(scale)).to(cuda), torch.from_numpy(pad(bias)).to(cuda)
+    out = torch.empty((B, H // stride, Wd // stride, Cout), dtype=torch.float16, device=cuda)
+    ns["conv2d_bn_leaky"](xd.data_ptr(), wd.data_ptr(), sd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, Wd, Cin, Cout, k,
+                          stride, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = _ref(x.astype(np.float32), w.astype(np.float32), scale, bias, stride, "leaky", 0.1)
+    got = out.cpu().numpy().astype(np.float64)
+    assert (np.abs(got - ref) <= 1e-3 * max(1.0, np.abs(ref).max()) + 2.0 ** -10 * np.abs(ref)).all()

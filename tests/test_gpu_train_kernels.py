@@ -105,11 +105,24 @@ def test_conv_backward(cuda, case):
     assert dxd.shape == dx_ref.shape
     tol = 2e-3 * max(1.0, np.abs(dx_ref).max()) + 2.0 ** -9 * np.abs(dx_ref)
     assert (np.abs(dxd - dx_ref) <= tol).all(), np.abs(dxd - dx_ref).max()
+    # the one-call export od_conv2d_bwd_data runs the same kernels: bit-identical
+    import ctypes as C
+    from object_detector_amd import _lib
+    from object_detector_amd.net import Context
+    ctx = Context.get(cuda)
+    dx1 = torch.empty_like(dx)
+    _lib.check(ctx.lib.od_conv2d_bwd_data(ctx.handle, dzd.data_ptr(), wb.data_ptr(), None, dx1.data_ptr(), B, Ho, Wo, Cin,
+                                          Cout, k, stride, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert torch.equal(dx1, dx)
     # gradient accumulation through the epilogue's residual input
     acc = torch.from_numpy(rng.normal(0, 1, dx_ref.shape).astype(np.float16)).to(cuda)
     dx2 = T.conv_packed(dzd, wb, ones, zeros, Cout, Cin, k, stride=stride, transposed=(stride == 2), res=acc,
                         res_mode="same").cpu().numpy().astype(np.float64)
     ref2 = dx_ref + acc.cpu().numpy().astype(np.float64)
+    acc1 = acc.clone()  # in place: dx_accumulate aliases dx
+    _lib.check(ctx.lib.od_conv2d_bwd_data(ctx.handle, dzd.data_ptr(), wb.data_ptr(), acc1.data_ptr(), acc1.data_ptr(), B, Ho,
+                                          Wo, Cin, Cout, k, stride, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert np.array_equal(acc1.cpu().numpy().astype(np.float64), dx2)
     assert (np.abs(dx2 - ref2) <= tol + 2.0 ** -9 * np.abs(ref2) + 1e-3).all()
     # backward-weight (f32, atomics: order noise only)
     dw = T.conv_bwd_weight(xd, dzd, Cin, Cout, k, stride).cpu().numpy()[:Cout, :k * k * Cin]
@@ -139,3 +152,26 @@ def test_down2_and_sgd(cuda):
     mr = 0.9 * m + (g / 128 + 1e-4 * w)
     np.testing.assert_allclose(md.cpu().numpy(), mr, rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(wd.cpu().numpy(), w - 0.1 * mr, rtol=1e-6, atol=1e-7)
+
+
+def test_bn_fold_bit_exact_vs_numpy(cuda):
+    """od_bn_fold = the loader's host-side fold (weights.fold_bn / oracle fold_bn), bit for bit."""
+    import ctypes as C
+    from object_detector_amd import _lib, weights as W
+    from object_detector_amd.net import Context
+    from oracle import network as onet
+    ctx = Context.get(cuda)
+    rng = np.random.default_rng(0)
+    for Cn in (32, 208, 1024, 5):
+        p = {"l.gamma": rng.uniform(0.1, 1.5, Cn).astype(np.float32), "l.beta": rng.normal(0, 0.1, Cn).astype(np.float32),
+             "l.mean": rng.normal(0, 0.5, Cn).astype(np.float32), "l.var": rng.uniform(0.01, 3.0, Cn).astype(np.float32),
+             "l.w": np.zeros((Cn, 1, 1, 8), np.float32)}
+        d = {k: torch.from_numpy(v).to(cuda) for k, v in p.items()}
+        sc, bi = torch.empty(Cn, device=cuda), torch.empty(Cn, device=cuda)
+        _lib.check(ctx.lib.od_bn_fold(ctx.handle, d["l.gamma"].data_ptr(), d["l.beta"].data_ptr(), d["l.mean"].data_ptr(),
+                                      d["l.var"].data_ptr(), W.BN_EPS, sc.data_ptr(), bi.data_ptr(), Cn,
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        rs, rb = onet.fold_bn(p, "l")
+        assert np.array_equal(sc.cpu().numpy(), rs) and np.array_equal(bi.cpu().numpy(), rb)
+        rs2, rb2 = W.fold_bn(p, "l")
+        assert np.array_equal(rs, rs2) and np.array_equal(rb, rb2)

@@ -29,10 +29,12 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("backbone_act", [("elu", 1.0), ("leaky", 0.1)], ids=["smooth", "leaky"])
 def test_training_step_matches_torch_oracle(cuda, backbone_act):
-    """Gradients of every parameter vs the float64 torch oracle.  With a smooth activation everywhere the f16 pipeline
-    agrees to < 1 %; with the backbone's LeakyReLU the kink makes ~1 % of the units take the other slope than in the
-    float64 oracle (their pre-activation differs by the accumulated f16 rounding), which alone moves the gradient
-    direction by a few % -- so the leaky variant only gets the loose bound."""
+    """Gradients of every parameter vs the float64 torch oracle: < 1 % on every segment, for both activations.
+    With the backbone's LeakyReLU a unit whose pre-activation is within the f16 pipeline's rounding noise of 0 takes the
+    other slope on the device than in float64 (tests/test_oracle_golden.py shows ONE such unit in 1.5 M moving some
+    segments by 0.6 % even between f32 and f64).  That is a property of the function, not an arithmetic error of the
+    kernels, so the oracle differentiates the device's own sign pattern (`slope_masks`); the moved units are COUNTED and
+    bounded, and the unmasked comparison is reported beside it."""
     from object_detector_amd.trainer import Trainer
     from oracle.train_ref import TorchDetector
     B, S = 2, 96
@@ -43,20 +45,27 @@ def test_training_step_matches_torch_oracle(cuda, backbone_act):
     losses = tr.loss(y).clone()
     grads = tr.backward()
     torch.cuda.synchronize()
-    ref_losses, ref_grads, ref_pred = TorchDetector(params, backbone_act=backbone_act).loss_and_grads(x, y.cpu().numpy())
+    masks = {n.name: (n.z.float() * n.scale + n.shift > 0).cpu().numpy() for n in tr.nodes if n.act and n.act[0] == "leaky"}
+    assert len(masks) == (52 if backbone_act[0] == "leaky" else 0)
+    ref = TorchDetector(params, backbone_act=backbone_act, slope_masks=masks)
+    ref_losses, ref_grads, ref_pred = ref.loss_and_grads(x, y.cpu().numpy())
     assert np.abs(pred.cpu().numpy() - ref_pred).max() <= 3e-2 * max(1.0, np.abs(ref_pred).max())
     np.testing.assert_allclose(losses.cpu().numpy(), ref_losses, rtol=3e-2)
     g = grads.cpu().numpy() / 256.0
-    worst = {}
-    for (name, kind), (o, n) in tr.seg.items():
-        worst[(name, kind)] = _rel(g[o:o + n], ref_grads[f"{name}.{kind}"].reshape(-1))
+
+    def worst_vs(rg):
+        return {(name, kind): _rel(g[o:o + n], rg[f"{name}.{kind}"].reshape(-1)) for (name, kind), (o, n) in tr.seg.items()}
+    worst = worst_vs(ref_grads)
     top = sorted(worst.items(), key=lambda kv: -kv[1])
     print("worst relative gradient errors:", top[:5], "median", np.median(list(worst.values())))
-    if backbone_act[0] == "elu":
-        assert max(worst.values()) < 0.01, top[:5]
-    else:
-        assert max(v for (n, k), v in worst.items() if not n.startswith("b.")) < 0.01  # neck / head are smooth (ELU)
-        assert max(worst.values()) < 0.15, top[:5]
+    assert max(worst.values()) < 0.01, top[:5]
+    if backbone_act[0] == "leaky":
+        flips, units = sum(ref.flips.values()), sum(ref.units.values())
+        plain = worst_vs(TorchDetector(params, backbone_act=backbone_act).loss_and_grads(x, y.cpu().numpy())[1])
+        print(f"units on the other side of the kink than in float64: {flips} of {units} ({flips / units:.2e}); "
+              f"without the mask the worst segment differs by {max(plain.values()):.3f}")
+        assert 0 < flips < 0.02 * units
+        assert max(plain.values()) < 0.15
 
 
 def test_sgd_step_lowers_loss_and_exports(cuda):
