@@ -31,6 +31,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=5,
+                    help="the K-step timed loop is repeated this many times (each bracketed by barrier + synchronize); the "
+                         "line reports the MEDIAN repetition")
     ap.add_argument("--size", type=int, default=320)
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 32 @320, 16 @640)")
     ap.add_argument("--graph", action="store_true", help="replay the network as a hipGraph")
@@ -38,19 +41,43 @@ def parse():
                     help="batches in flight on separate HIP streams (1 = every step waits for the previous one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the `extra` block (the other configurations of BASELINE.json's metric: 640x640 batch 16, "
+                         "batch 1 at both sizes, the training steps)")
     ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="train = BASELINE.json configs[3]/[4]: full training step, batch 32 (320) / 16 (640) per GPU")
+    ap.add_argument("--grad-payload", default="f32", choices=["f32", "bf16"],
+                    help="train: gradient all-reduce payload (bf16 = BASELINE.json configs[4])")
     return ap.parse_args()
 
 
-def cpu_baseline(size, seconds):
-    """The CPU oracle on this host's cores, same workload shape, bounded sample."""
-    from oracle import network as onet
-    from oracle import nms as onms
-    from oracle import postprocess as opp
-    # threads actually usable: the affinity mask capped by the cgroup CPU quota (a 16-core share of a 256-thread host ran
-    # torch's default 128 threads ~6x slower than 16 threads do)
+def launch_ranks(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks OURSELVES (one process per GPU,
+    `torch.distributed.run`, rendezvous on 127.0.0.1) and forward their output and exit code.  This parent has not made
+    and will not make a GPU call (torch.cuda.device_count() does not initialise the runtime), so nothing that touched the
+    GPU is ever re-executed.  The knob this stands for is the reference's use_multi_gpu=True (voc_validate.py:26)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ndev = torch.cuda.device_count()
+    if ndev < a.gpus and "OD_BENCH_BACKEND" not in env:
+        # fewer GPUs than ranks (a rehearsal on a 1-GPU box): ranks share devices, which RCCL cannot do -> gloo collectives
+        print(f"bench.py: {a.gpus} ranks on {ndev} GPU(s): rehearsal with the gloo backend (ranks share a device)",
+              file=sys.stderr)
+        env["OD_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def usable_cores():
+    """threads actually usable: the affinity mask capped by the cgroup CPU quota (a 16-core share of a 256-thread host ran
+    torch's default 128 threads ~6x slower than 16 threads do)"""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -58,6 +85,15 @@ def cpu_baseline(size, seconds):
             cores = max(1, min(cores, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
+    return cores
+
+
+def cpu_baseline(size, seconds):
+    """The CPU oracle on this host's cores, same workload shape, bounded sample."""
+    from oracle import network as onet
+    from oracle import nms as onms
+    from oracle import postprocess as opp
+    cores = usable_cores()
     torch.set_num_threads(cores)
     params = onet.init_weights(seed=2)
     runner = onet.Runner(params, storage="f32")
@@ -84,21 +120,39 @@ def cpu_baseline(size, seconds):
                       f"same Darknet53+neck+head + numpy decode/top-k/NMS (CPU restatement, not the reference)"}
 
 
-def train_bench(a, rank, world, dev):
-    """One step = prior-box assignment + forward (BN training mode) + loss + backward + gradient all-reduce (RCCL) + SGD."""
-    from object_detector_amd import weights as W
-    from object_detector_amd.net import Context
+def _barrier(world):
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+
+def timed_reps(step, steps, warmup, reps, world, dev):
+    """W untimed warm-up steps, then `reps` repetitions of EXACTLY `steps` steps, each bracketed by barrier +
+    torch.cuda.synchronize() on both sides; every repetition's time is the MAX over ranks.  -> sorted list of seconds."""
+    for _ in range(warmup):
+        step()
+    out = []
+    for _ in range(max(1, reps)):
+        _barrier(world)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        _barrier(world)
+        out.append(time.perf_counter() - t0)
+    if world > 1:
+        nccl = torch.distributed.get_backend() == "nccl"
+        t = torch.tensor(out, dtype=torch.float64, device=dev if nccl else "cpu")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        out = [float(v) for v in t.tolist()]
+    return sorted(out)
+
+
+def _median(xs):
+    return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
+
+
+def bench_annotations(batch, size, rng):
     from object_detector_amd.pb import ObjectsAnnotation
-    from object_detector_amd.trainer import Trainer, init_comm
-    size = a.size
-    batch = a.batch or (32 if size <= 320 else 16)
-    comm = None
-    if world > 1 and torch.distributed.get_backend() == "nccl":
-        comm, _ = init_comm(Context.get(dev))  # RCCL communicator through the C ABI (od_comm_*)
-    tr = Trainer(W.random_init(2), batch, (size, size), device=dev, lr=1e-3, momentum=0.9, loss_scale=1024.0, comm=comm,
-                 world_size=world)
-    rng = np.random.default_rng(1000 + rank)
-    x = torch.from_numpy(rng.integers(0, 256, (batch, size, size, 3), dtype=np.uint8)).to(dev)
     anns = []
     for _ in range(batch):
         n = int(np.clip(1 + rng.poisson(1.5), 1, 10))
@@ -106,42 +160,119 @@ def train_bench(a, rank, world, dev):
         wh = np.exp(rng.uniform(np.log(0.05), np.log(0.9), (n, 2)))
         anns.append(ObjectsAnnotation(None, size, size, rng.integers(0, 20, n),
                                       np.clip(np.concatenate([c - wh / 2, c + wh / 2], 1), 0, 1).astype(np.float32)))
+    return anns
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        tr.step(x, anns)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        tr.step(x, anns)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        nccl = torch.distributed.get_backend() == "nccl"
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if nccl else "cpu")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    losses = tr.losses.cpu().numpy()
+TRAIN_FLOPS_IMG_320 = 3.0 * (29.01e9 + 7.2e9)  # fwd + bwd-data + bwd-weight of backbone + neck/head, per 320x320 image
+
+
+def run_train(params, size, batch, steps, warmup, reps, rank, world, dev, comm=None, grad_payload="f32"):
+    """One step = prior-box assignment + forward (BN training mode) + loss + backward + gradient all-reduce + SGD."""
+    from object_detector_amd.trainer import Trainer
+    tr = Trainer(params, batch, (size, size), device=dev, lr=1e-3, momentum=0.9, loss_scale=1024.0, comm=comm,
+                 world_size=world, grad_payload=grad_payload)
+    rng = np.random.default_rng(1000 + rank)
+    x = torch.from_numpy(rng.integers(0, 256, (batch, size, size, 3), dtype=np.uint8)).to(dev)
+    anns = bench_annotations(batch, size, rng)
+    times = timed_reps(lambda: tr.step(x, anns), steps, warmup, reps, world, dev)
+    el = _median(times)
+    flops_img = TRAIN_FLOPS_IMG_320 * (size / 320.0) ** 2
+    rec = {"value": round(world * batch * steps / el, 2), "ms_per_step": round(el / steps * 1e3, 3),
+           "ms_per_step_reps": [round(t / steps * 1e3, 3) for t in times],
+           "tflops_per_gpu": round(flops_img * batch * steps / el / 1e12, 2),
+           "frac": round(flops_img * batch * steps / el / 1e12 / PEAK_F16_TFLOPS, 4),
+           "loss_total": float(tr.losses.cpu().numpy()[3]), "skipped_steps": tr.skipped_steps,
+           "gradient_buckets": len(tr._buckets), "grad_payload": tr.grad_payload}
+    return rec, tr
+
+
+def train_bench(a, rank, world, dev):
+    from object_detector_amd import _lib, weights as W
+    from object_detector_amd.net import Context
+    from object_detector_amd.trainer import init_comm
+    import ctypes as C
+    size = a.size
+    batch = a.batch or (32 if size <= 320 else 16)
+    comm, seen = None, world
+    if world > 1 and torch.distributed.get_backend() == "nccl":
+        ctx = Context.get(dev)
+        comm, _ = init_comm(ctx)  # RCCL communicator through the C ABI (od_comm_*)
+        r_, n_ = C.c_int(), C.c_int()
+        _lib.check(ctx.lib.od_comm_count(comm, C.byref(r_), C.byref(n_)), "od_comm_count")
+        seen = n_.value
+        assert seen == world and r_.value == rank, f"RCCL reports rank {r_.value} of {seen}, launcher said {rank} of {world}"
+    elif world > 1:
+        seen = torch.distributed.get_world_size()
+    rec, _tr = run_train(W.random_init(2), size, batch, a.steps, a.warmup, a.reps, rank, world, dev, comm, a.grad_payload)
     if rank == 0:
-        flops_img = 3.0 * (29.01e9 + 7.2e9) * (size / 320.0) ** 2  # fwd + bwd-data + bwd-weight
         print(json.dumps({
-            "metric": "train_images_per_sec", "value": round(world * batch * a.steps / elapsed, 2), "unit": "images/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "metric": "train_images_per_sec", "value": rec["value"], "unit": "images/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "reps": a.reps, "ms_per_step": rec["ms_per_step"],
+            "ms_per_step_reps": rec["ms_per_step_reps"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"Darknet53 {size}x{size} training step (assign + fwd + focal/CE/smooth-L1 + bwd + "
                                    f"RCCL all-reduce + SGD), batch {batch} per GPU, synthetic data",
                        "global_batch": world * batch, "input_size": size, "parallelism": f"dp{world}",
-                       "loss_total": float(losses[3])},
-            "roofline": {"bound": "mfma", "achieved": round(flops_img * world * batch * a.steps / elapsed / 1e12 / world, 2),
-                         "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(flops_img * batch * a.steps / elapsed / 1e12 / PEAK_F16_TFLOPS, 4),
+                       "ranks_seen_by_collective_backend": seen,
+                       "backend": torch.distributed.get_backend() if world > 1 else None,
+                       "grad_payload": rec["grad_payload"], "gradient_buckets": rec["gradient_buckets"],
+                       "loss_total": rec["loss_total"], "skipped_steps": rec["skipped_steps"]},
+            "roofline": {"bound": "mfma", "achieved": rec["tflops_per_gpu"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": rec["frac"],
                          "note": "whole-step algorithmic conv flops / step time (not a single kernel)", "traffic": None}}))
+    if comm is not None:
+        torch.cuda.synchronize()
+        Context.get(dev).lib.od_comm_destroy(comm)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def run_infer(params, size, batch, inflight, steps, warmup, reps, rank, world, dev, graph=False):
+    """One step = one predict pass over a uint8 batch resident in HBM (network + decode + top-K + NMS).  With inflight > 1
+    the step is queued on the next pipeline's stream and overlaps the tail of the previous steps; every step of a
+    repetition is complete before its closing synchronize."""
+    from object_detector_amd.detector import ObjectDetector
+    od = ObjectDetector(params, batch, (size, size), device=dev, use_multi_gpu=world > 1, n_inflight=inflight)
+    rng = np.random.default_rng(1000 + rank)  # each rank its own shard of synthetic images
+    x = torch.from_numpy(rng.integers(0, 256, (batch, size, size, 3), dtype=np.uint8)).to(dev)
+    if od.n_inflight > 1:
+        step = lambda: od.submit(x, conf_threshold=0.01, graph=graph)  # noqa: E731
+    else:
+        step = lambda: od.predict_batch_device(x, conf_threshold=0.01, graph=graph)  # noqa: E731
+    times = timed_reps(step, steps, warmup, reps, world, dev)
+    return od, times
+
+
+def extra_block(params, a, dev):
+    """The rest of BASELINE.json's metric ("images/sec at 320x320 & 640x640 batch-1 and batch-32" + the training configs),
+    driver-timed in the same run: each entry is timed like the main line (warm-up, `reps` repetitions of K steps between
+    synchronizes, median) on ONE GPU; `frac` = whole-network algorithmic conv flops / step time / 2.5 PFLOP/s."""
+    out = {}
+    net_flops_320 = 29.01e9 + 7.2e9
+
+    def infer(key, size, batch, inflight, steps):
+        od, times = run_infer(params, size, batch, inflight, steps, max(3, steps // 5), a.reps, 0, 1, dev)
+        el = _median(times)
+        fl = net_flops_320 * (size / 320.0) ** 2 * batch
+        out[key] = {"workload": f"inference {size}x{size} batch {batch}, {inflight} in flight", "images_per_sec": round(batch * steps / el, 1),
+                    "ms_per_step": round(el / steps * 1e3, 4), "frac": round(fl * steps / el / 1e12 / PEAK_F16_TFLOPS, 4)}
+        del od
+        torch.cuda.empty_cache()
+
+    infer("infer_320_b32_inflight1", 320, 32, 1, 20)
+    infer("infer_640_b16_inflight3", 640, 16, 3, 12)
+    infer("infer_640_b16_inflight1", 640, 16, 1, 12)
+    infer("infer_320_b1_inflight3", 320, 1, 3, 100)
+    infer("infer_320_b1_inflight1", 320, 1, 1, 100)
+    infer("infer_640_b1_inflight3", 640, 1, 3, 60)
+    infer("infer_640_b1_inflight1", 640, 1, 1, 60)
+    for key, size, batch, steps in (("train_320_b32", 320, 32, 6), ("train_640_b16", 640, 16, 4)):
+        rec, tr = run_train(params, size, batch, steps, 2, min(a.reps, 3), 0, 1, dev)
+        out[key] = {"workload": f"training step {size}x{size} batch {batch} (assign + fwd + loss + bwd + SGD), 1 GPU",
+                    "images_per_sec": rec["value"], "ms_per_step": rec["ms_per_step"], "frac": rec["frac"]}
+        del tr
+        torch.cuda.empty_cache()
+    return out
 
 
 def _workgroups(kernel_name, M, N):
@@ -160,57 +291,41 @@ def _workgroups(kernel_name, M, N):
 
 def main():
     a = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL: before the HIP runtime comes up
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a))  # this process only waits for its N rank processes
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != a.gpus and world > 1:
-        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
     ndev = max(1, torch.cuda.device_count())
     dev = torch.device(f"cuda:{local_rank % ndev}")  # one rank per GPU (the modulo only matters for 1-GPU rehearsals)
-    torch.cuda.set_device(dev)
     backend = os.environ.get("OD_BENCH_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; "gloo" to rehearse on one GPU
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=dev)
         else:
             torch.distributed.init_process_group(backend)
+    torch.cuda.set_device(dev)
 
     if a.mode == "train":
         return train_bench(a, rank, world, dev)
 
-    from object_detector_amd.detector import ObjectDetector
+    from object_detector_amd import weights as W
     size = a.size
     batch = a.batch or (32 if size <= 320 else 16)
-    od = ObjectDetector.synthetic(batch, (size, size), seed=2, device=dev, use_multi_gpu=world > 1,
-                                  n_inflight=a.inflight)
-    rng = np.random.default_rng(1000 + rank)  # each rank its own shard of synthetic images
-    x = torch.from_numpy(rng.integers(0, 256, (batch, size, size, 3), dtype=np.uint8)).to(dev)
-
-    def step():
-        # one pass of the hot path over one batch; with --inflight > 1 the step is queued on the next pipeline's stream and
-        # overlaps the tail of the previous steps (every step is complete before the closing synchronize)
-        if od.n_inflight > 1:
-            return od.submit(x, conf_threshold=0.01, graph=a.graph)
-        return od.predict_batch_device(x, conf_threshold=0.01, graph=a.graph)
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    params = W.random_init(2)
+    od, times = run_infer(params, size, batch, a.inflight, a.steps, a.warmup, a.reps, rank, world, dev, a.graph)
+    elapsed = _median(times)
+    ranks_seen = world
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # no collective on the inference data path; what the process group itself reports, summed over the ranks
+        t = torch.ones(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        torch.distributed.all_reduce(t)
+        ranks_seen = int(round(float(t.item())))
+        assert ranks_seen == torch.distributed.get_world_size() == world
     keep_count = od.post.keep_count.cpu().numpy()
 
     # ---- roofline of the dominant kernel: hipEvents around every op of the plan, on the launch stream ----------
@@ -250,13 +365,14 @@ def main():
     traffic = None
     try:
         import pathlib
-        pj = pathlib.Path(__file__).resolve().parent / "profiles" / "r01" / "pmc_traffic.json"
-        if size == 320 and batch == 32 and pj.exists():
+        prof = pathlib.Path(__file__).resolve().parent / "profiles"
+        pj = next((q for q in (prof / "r02" / "pmc_traffic.json", prof / "r01" / "pmc_traffic.json") if q.exists()), None)
+        if size == 320 and batch == 32 and pj is not None:
             for kname, rec in json.loads(pj.read_text())["kernels"].items():
                 if dom in kname:
                     traffic = {"hbm_bytes_per_launch": rec["hbm_bytes_per_launch"],
                                "algorithmic_bytes_per_launch": round(g["bytes"] / g["n"]),
-                               "source": "profiles/r01/pmc_traffic.json"}
+                               "source": str(pj.relative_to(prof.parent))}
     except Exception:
         traffic = None
     if a.layers and rank == 0:
@@ -279,7 +395,9 @@ def main():
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
+            "reps": a.reps,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "ms_per_step_reps": [round(t / a.steps * 1e3, 4) for t in times],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -290,6 +408,7 @@ def main():
                                    f"random-init weights",
                        "global_batch": world * batch, "input_size": size, "parallelism": f"dp{world}",
                        "graph": bool(a.graph), "batches_in_flight": od.n_inflight,
+                       "ranks_seen_by_process_group": ranks_seen, "backend": backend if world > 1 else None,
                        "kept_boxes_rank0_img0": int(keep_count[0])},
             "roofline": {"bound": "mfma", "kernel": dom, "launches_per_step": g["n"],
                          "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
@@ -303,6 +422,10 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(size, a.cpu_seconds)
+        if world == 1 and not a.no_extra:
+            del od
+            torch.cuda.empty_cache()
+            out["extra"] = extra_block(params, a, dev)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

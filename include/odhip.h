@@ -45,6 +45,7 @@ extern "C" {
 
 #define OD_DT_F16 0
 #define OD_DT_F32 1
+#define OD_DT_BF16 2 /* od_allreduce payload only */
 
 typedef struct od_ctx od_ctx;
 
@@ -190,6 +191,13 @@ int od_nms(od_ctx* ctx, const float* boxes, const uint64_t* keys, const int32_t*
            int K, float iou_threshold, int strict, int max_det, int32_t* keep_flat, int32_t* keep_count,
            void* workspace, size_t workspace_bytes, void* stream);
 
+/* The kept detections of a batch as ONE dense record block, so that `predict` copies a single buffer back per batch
+ * (reference voc_validate.py:27 returns per-image classes / confs / bboxes):
+ *   out f32 [B][1 + 6*max_det]: out[b][0] = keep_count[b] (int bits); row r = out[b][1 + 6r ...] =
+ *   {flat index p*NC+c (int bits; -1 beyond the count), conf[b][flat], boxes[b][p][0..3]} in rank order. */
+int od_gather_detections(od_ctx* ctx, const float* conf, const float* boxes, const int32_t* keep_flat,
+                         const int32_t* keep_count, int B, int P, int NC, int max_det, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K9: prior-box assignment + target encoding = od.pb.encode_truth (reference check_assign.py:21,25-27).
  *   priors f32 [P,4]; gt_boxes f32 [B,Gmax,4] corner form, normalised; gt_classes i32 [B,Gmax]; gt_counts i32 [B]
@@ -295,8 +303,16 @@ typedef struct od_pack_layer {
   void* w_bwd;      /* f16 [Cin_pad][Kpad_t] or NULL */
   int32_t Cout, Cin, ksize, pad_;
 } od_pack_layer;
+/* skip_if_nonzero (DEVICE int32, may be NULL): when *skip_if_nonzero != 0 the launch leaves w and m untouched -- the flag
+ * od_grad_nonfinite writes, so that one f16 overflow in the loss-scaled backward pass cannot poison the master weights */
 int od_sgd_step_multi(od_ctx* ctx, float* w, float* m, const float* g, const od_sgd_seg* segs, int nseg, float momentum,
-                      float inv_loss_scale, void* stream);
+                      float inv_loss_scale, const int32_t* skip_if_nonzero, void* stream);
+/* flag[0] (DEVICE int32) = 1 when any of g[0..n) is Inf / NaN, else 0.  Run it on the flat gradient buffer AFTER the
+ * all-reduce: a non-finite value on one rank reaches every rank through the sum, so all ranks skip the same step. */
+int od_grad_nonfinite(od_ctx* ctx, const float* g, long long n, int32_t* flag, void* stream);
+/* f32 <-> bf16 (round to nearest even) for the bf16 gradient payload of od_allreduce(OD_DT_BF16) */
+int od_cast_f32_bf16(od_ctx* ctx, const float* src, void* dst, long long n, void* stream);
+int od_cast_bf16_f32(od_ctx* ctx, const void* src, float* dst, long long n, void* stream);
 int od_pack_weights_multi(od_ctx* ctx, const float* w, const od_pack_layer* layers, int nlayers, void* stream);
 
 /* first layer's weight gradient: dw f32 [32][27] += dz^T . shifted(x_u8) * in_scale (no dX: the input is the image) */
@@ -312,7 +328,8 @@ typedef struct od_comm od_comm;
 int od_comm_unique_id_bytes(void);
 int od_comm_get_unique_id(void* out, int bytes);
 int od_comm_init(od_ctx* ctx, int rank, int nranks, const void* unique_id, od_comm** out);
-int od_allreduce(od_comm* comm, void* buf, long long count, int dtype, void* stream);
+int od_allreduce(od_comm* comm, void* buf, long long count, int dtype, void* stream); /* dtype: OD_DT_F32 / F16 / BF16 */
+int od_comm_count(od_comm* comm, int* rank, int* nranks); /* as RCCL reports them (ncclCommUserRank / ncclCommCount) */
 int od_comm_destroy(od_comm* comm);
 
 /* ------------------------------------------------------------------------------------------------

@@ -14,7 +14,7 @@ LIB_PATH = _HERE / "libodhip.so"
 
 OD_ACT_LINEAR, OD_ACT_LEAKY, OD_ACT_ELU = 0, 1, 2
 OD_RES_NONE, OD_RES_SAME, OD_RES_UP2 = 0, 1, 2
-OD_DT_F16, OD_DT_F32 = 0, 1
+OD_DT_F16, OD_DT_F32, OD_DT_BF16 = 0, 1, 2
 OD_OP_CONV, OD_OP_CONV_FIRST, OD_OP_BNECK, OD_OP_STEM = 1, 2, 3, 4
 
 ACT_ENUM = {None: OD_ACT_LINEAR, "linear": OD_ACT_LINEAR, "leaky": OD_ACT_LEAKY, "elu": OD_ACT_ELU}
@@ -122,6 +122,8 @@ _PROTOS = {
     "od_nms_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "od_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                          C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "od_gather_detections": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_void_p, C.c_void_p]),
     "od_assign_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "od_assign_anchors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
@@ -157,7 +159,10 @@ _PROTOS = {
                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "od_wgrad_reduce_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "od_sgd_step_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
-                                    C.c_float, C.c_void_p]),
+                                    C.c_float, C.c_void_p, C.c_void_p]),
+    "od_grad_nonfinite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
+    "od_cast_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "od_cast_bf16_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
     "od_pack_weights_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "od_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p]),
@@ -167,6 +172,7 @@ _PROTOS = {
     "od_comm_get_unique_id": (C.c_int, [C.c_void_p, C.c_int]),
     "od_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "od_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
+    "od_comm_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "od_comm_destroy": (C.c_int, [C.c_void_p]),
     "od_aug_params_bytes": (C.c_int, []),
     "od_augment_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

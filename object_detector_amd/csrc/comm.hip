@@ -48,12 +48,21 @@ extern "C" int od_comm_init(od_ctx* ctx, int rank, int nranks, const void* uniqu
   return OD_OK;
 }
 
-// dtype: OD_DT_F32 or OD_DT_F16; sum over ranks, in place
+// what RCCL itself reports for this communicator (bench.py puts it in its JSON line: "RCCL saw N ranks")
+extern "C" int od_comm_count(od_comm* comm, int* rank, int* nranks) {
+  OD_REQUIRE(comm && rank && nranks, "od_comm_count: bad argument");
+  OD_CHECK_NCCL(ncclCommUserRank(comm->comm, rank));
+  OD_CHECK_NCCL(ncclCommCount(comm->comm, nranks));
+  return OD_OK;
+}
+
+// dtype: OD_DT_F32, OD_DT_F16 or OD_DT_BF16; sum over ranks, in place
 extern "C" int od_allreduce(od_comm* comm, void* buf, long long count, int dtype, void* stream) {
   OD_REQUIRE(comm && buf && count > 0, "od_allreduce: bad argument");
-  OD_REQUIRE(dtype == OD_DT_F32 || dtype == OD_DT_F16, "od_allreduce: dtype must be OD_DT_F32 or OD_DT_F16");
-  OD_CHECK_NCCL(ncclAllReduce(buf, buf, (size_t)count, dtype == OD_DT_F32 ? ncclFloat32 : ncclFloat16, ncclSum, comm->comm,
-                              (hipStream_t)stream));
+  OD_REQUIRE(dtype == OD_DT_F32 || dtype == OD_DT_F16 || dtype == OD_DT_BF16,
+             "od_allreduce: dtype must be OD_DT_F32, OD_DT_F16 or OD_DT_BF16");
+  const ncclDataType_t t = dtype == OD_DT_F32 ? ncclFloat32 : (dtype == OD_DT_F16 ? ncclFloat16 : ncclBfloat16);
+  OD_CHECK_NCCL(ncclAllReduce(buf, buf, (size_t)count, t, ncclSum, comm->comm, (hipStream_t)stream));
   return OD_OK;
 }
 

@@ -107,7 +107,45 @@ __global__ __launch_bounds__(256) void od_up2_add(const f16* __restrict__ a, con
   }
 }
 
+// one workgroup per image: row r of out[b] = {flat index (int bits), conf, x1, y1, x2, y2} of kept detection r
+__global__ __launch_bounds__(256) void od_gather_det(const float* __restrict__ conf, const float* __restrict__ boxes,
+                                                     const int32_t* __restrict__ keep_flat,
+                                                     const int32_t* __restrict__ keep_count, int P, int NC, int max_det,
+                                                     float* __restrict__ out) {
+  const int b = blockIdx.x;
+  const int n = keep_count[b];
+  float* o = out + (size_t)b * (1 + 6 * (size_t)max_det);
+  if (threadIdx.x == 0) o[0] = __int_as_float(n);
+  for (int r = threadIdx.x; r < max_det; r += 256) {
+    float* row = o + 1 + 6 * (size_t)r;
+    if (r < n) {
+      const int flat = keep_flat[(size_t)b * max_det + r];
+      const int p = flat / NC;
+      const float* bx = boxes + ((size_t)b * P + p) * 4;
+      row[0] = __int_as_float(flat);
+      row[1] = conf[(size_t)b * P * NC + flat];
+      row[2] = bx[0];
+      row[3] = bx[1];
+      row[4] = bx[2];
+      row[5] = bx[3];
+    } else {
+      row[0] = __int_as_float(-1);
+      row[1] = row[2] = row[3] = row[4] = row[5] = 0.f;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int od_gather_detections(od_ctx* ctx, const float* conf, const float* boxes, const int32_t* keep_flat,
+                                    const int32_t* keep_count, int B, int P, int NC, int max_det, float* out, void* stream) {
+  OD_REQUIRE(ctx && conf && boxes && keep_flat && keep_count && out, "od_gather_detections: null argument");
+  OD_REQUIRE(B > 0 && P > 0 && NC > 0 && max_det > 0, "od_gather_detections: bad dims");
+  hipLaunchKernelGGL(od_gather_det, dim3(B), dim3(256), 0, (hipStream_t)stream, conf, boxes, keep_flat, keep_count, P, NC,
+                     max_det, out);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
 
 extern "C" int od_head_postprocess(od_ctx* ctx, const float* pred, const float* priors, float* conf, float* boxes,
                                    int B, int P, int NC, float loc_scale, int clip, void* stream) {

@@ -409,7 +409,9 @@ __global__ __launch_bounds__(256) void od_pack_w_k(const float* __restrict__ w, 
 
 // multi-tensor forms: blockIdx.y = tensor, blockIdx.x strides over its elements
 __global__ __launch_bounds__(256) void od_sgd_multi_k(float* __restrict__ w, float* __restrict__ m, const float* __restrict__ g,
-                                                      const od_sgd_seg* __restrict__ segs, float momentum, float inv_scale) {
+                                                      const od_sgd_seg* __restrict__ segs, float momentum, float inv_scale,
+                                                      const int32_t* __restrict__ skip) {
+  if (skip && *skip) return;  // a non-finite gradient was found (od_grad_nonfinite): leave weights and momentum untouched
   const od_sgd_seg sg = segs[blockIdx.y];
   float* ws = w + sg.offset;
   float* ms = m + sg.offset;
@@ -656,10 +658,68 @@ extern "C" int od_sgd_step(od_ctx* ctx, float* w, float* m, const float* g, long
 }
 
 extern "C" int od_sgd_step_multi(od_ctx* ctx, float* w, float* m, const float* g, const od_sgd_seg* segs, int nseg,
-                                 float momentum, float inv_loss_scale, void* stream) {
+                                 float momentum, float inv_loss_scale, const int32_t* skip_if_nonzero, void* stream) {
   OD_REQUIRE(ctx && w && m && g && segs && nseg > 0 && nseg <= 65535, "od_sgd_step_multi: bad argument");
   hipLaunchKernelGGL(od_sgd_multi_k, dim3(256, nseg), dim3(256), 0, (hipStream_t)stream, w, m, g, segs, momentum,
-                     inv_loss_scale);
+                     inv_loss_scale, skip_if_nonzero);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
+// flag[0] = 1 when any of g[0..n) is Inf or NaN, else 0 (flag is cleared by the first launch, set by the second)
+__global__ void od_flag_clear_k(int32_t* flag) { *flag = 0; }
+__global__ __launch_bounds__(256) void od_grad_nonfinite_k(const float* __restrict__ g, long long n4, long long n,
+                                                           int32_t* __restrict__ flag) {
+  bool bad = false;
+  const f32x4* g4 = (const f32x4*)g;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 v = g4[i];
+    // exponent field all ones <=> Inf or NaN
+    bad = bad || (__float_as_uint(v.x) & 0x7f800000u) == 0x7f800000u || (__float_as_uint(v.y) & 0x7f800000u) == 0x7f800000u ||
+          (__float_as_uint(v.z) & 0x7f800000u) == 0x7f800000u || (__float_as_uint(v.w) & 0x7f800000u) == 0x7f800000u;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4))
+    bad = bad || (__float_as_uint(g[4 * n4 + threadIdx.x]) & 0x7f800000u) == 0x7f800000u;
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+extern "C" int od_grad_nonfinite(od_ctx* ctx, const float* g, long long n, int32_t* flag, void* stream) {
+  OD_REQUIRE(ctx && g && flag && n > 0, "od_grad_nonfinite: bad argument");
+  OD_REQUIRE(((uintptr_t)g & 15) == 0, "od_grad_nonfinite: g must be 16-byte aligned");
+  hipLaunchKernelGGL(od_flag_clear_k, dim3(1), dim3(1), 0, (hipStream_t)stream, flag);
+  OD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(od_grad_nonfinite_k, dim3(grid_for(n / 4 / 4 + 1)), dim3(256), 0, (hipStream_t)stream, g, n / 4, n, flag);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
+// f32 <-> bf16 (round to nearest even; Inf / NaN preserved) for the bf16 gradient all-reduce payload (BASELINE.json
+// configs[4]; SURVEY.md §0.1 "bf16 for the all-reduce payload")
+__global__ __launch_bounds__(256) void od_f32_to_bf16_k(const float* __restrict__ src, uint16_t* __restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const uint32_t u = __float_as_uint(src[i]);
+    uint32_t r;
+    if ((u & 0x7fffffffu) > 0x7f800000u) r = (u >> 16) | 0x40u;  // NaN stays NaN
+    else r = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    dst[i] = (uint16_t)r;
+  }
+}
+__global__ __launch_bounds__(256) void od_bf16_to_f32_k(const uint16_t* __restrict__ src, float* __restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    dst[i] = __uint_as_float((uint32_t)src[i] << 16);
+}
+
+extern "C" int od_cast_f32_bf16(od_ctx* ctx, const float* src, void* dst, long long n, void* stream) {
+  OD_REQUIRE(ctx && src && dst && n > 0, "od_cast_f32_bf16: bad argument");
+  hipLaunchKernelGGL(od_f32_to_bf16_k, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst, n);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
+extern "C" int od_cast_bf16_f32(od_ctx* ctx, const void* src, float* dst, long long n, void* stream) {
+  OD_REQUIRE(ctx && src && dst && n > 0, "od_cast_bf16_f32: bad argument");
+  hipLaunchKernelGGL(od_bf16_to_f32_k, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, dst,
+                     n);
   OD_CHECK_LAUNCH();
   return OD_OK;
 }

@@ -81,8 +81,8 @@ class _Pipeline:
 class ObjectDetector:
     def __init__(self, params, batch_size=16, input_size=(320, 320), keep_aspect=False, strict_nms=False,
                  use_multi_gpu=True, device=None, prior_wh=None, n_inflight=None):
-        if device is None:
-            device = f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
+        if device is None:  # one process per GPU; the modulo only matters when several ranks rehearse on one GPU
+            device = f"cuda:{int(os.environ.get('LOCAL_RANK', 0)) % max(1, torch.cuda.device_count())}"
         if not torch.cuda.is_available():
             from ._lib import OdError
             raise OdError("ObjectDetector needs an MI355X (no GPU visible); there is no CPU path")
@@ -149,7 +149,7 @@ class ObjectDetector:
     def n_inflight(self):
         return len(self._pipes)
 
-    def submit(self, x_u8: torch.Tensor, conf_threshold=DEFAULT_CONF_THRESHOLD, graph=False) -> int:
+    def submit(self, x_u8: torch.Tensor, conf_threshold=DEFAULT_CONF_THRESHOLD, graph=False, gather=False) -> int:
         """Queue one batch on the next pipeline's stream and return its ticket.  Never blocks the host: a pipeline's new
         batch is stream-ordered behind its previous one (whose results it overwrites -- collect() them first)."""
         if not self._calibrated:
@@ -161,6 +161,8 @@ class ObjectDetector:
         with torch.cuda.stream(p.stream):
             pred = p.net.forward(x_u8, graph=graph)
             p.post.run(pred, conf_threshold)
+            if gather:
+                p.post.gather()  # kept detections -> one record block -> pinned host memory, still on this stream
             p.done.record()
         x_u8.record_stream(p.stream)
         return i
@@ -207,18 +209,12 @@ class ObjectDetector:
             p.stream.synchronize()
 
     def _collect(self, n_valid, scales=None, post=None):
+        """Per-image predictions of a collected batch from its pinned record block (submit(..., gather=True) queued the
+        gather kernel and the single device->host copy behind the NMS; no per-image device work or synchronisation)."""
         post = post or self.post
-        keep = post.keep_flat[:n_valid].cpu().numpy()
-        cnt = post.keep_count[:n_valid].cpu().numpy()
-        conf = post.conf
-        boxes = post.boxes
-        out = []
         NC = self.num_classes
-        for b in range(n_valid):
-            k = keep[b, :cnt[b]].astype(np.int64)
-            kt = torch.from_numpy(k).to(self.device)
-            confs = conf[b].reshape(-1)[kt].cpu().numpy()
-            bxs = boxes[b][kt // NC].cpu().numpy()
+        out = []
+        for b, (k, confs, bxs) in enumerate(post.detections_host(n_valid)):
             if scales is not None and scales[b] != (1.0, 1.0):  # keep_aspect: canvas coordinates -> image coordinates
                 sx, sy = scales[b]
                 bxs = np.clip(bxs / np.array([sx, sy, sx, sy], np.float32), 0.0, 1.0)
@@ -340,7 +336,7 @@ class ObjectDetector:
                 x = upload(bi)
                 if len(pending) == len(self._pipes):  # the pipeline about to be reused still holds unread results
                     drain(pending.pop(0))
-                pending.append((self.submit(x, conf_threshold), idx, scales))
+                pending.append((self.submit(x, conf_threshold, gather=True), idx, scales))
         finally:
             if own_pool is not None:
                 own_pool.shutdown(wait=True)

@@ -148,7 +148,15 @@ def apply_pixels_device(images, params, out_hw, device):
 
 
 class Generator:
-    def __init__(self, input_size, preprocess_input=None, encode_truth=None, random_erasing=True, device=None, workers=None):
+    def __init__(self, input_size, preprocess_input=None, encode_truth=None, random_erasing=True, device=None, workers=None,
+                 on_device=False):
+        # on_device (needs device=): X_batch stays a uint8 DEVICE tensor [B,H,W,3] -- what Trainer.step consumes -- instead of
+        # coming back to the host as numpy (the reference's generator feeds Keras from the host; the visual checkers
+        # check_generator.py / check_assign.py keep on_device=False and get numpy, as they index pixels on the host).
+        # With encode_truth = od.pb.encode_truth_device the targets stay on the device as well: no host round trip per step.
+        self.on_device = bool(on_device)
+        if self.on_device and device is None:
+            raise ValueError("on_device=True needs device=")
         self.input_size = tuple(int(v) for v in input_size)
         self.preprocess_input = preprocess_input
         self.encode_truth = encode_truth
@@ -196,7 +204,9 @@ class Generator:
                     raw = [f.result() for f in futs] if futs is not None else [self._load(X[i]) for i in idx]
                     prm = [sample_params(rng, y[i], self.random_erasing) if data_augmentation else AugParams() for i in idx]
                     if self.device is not None:
-                        xb = apply_pixels_device(raw, prm, self.input_size, self.device).cpu().numpy()
+                        xb = apply_pixels_device(raw, prm, self.input_size, self.device)
+                        if not self.on_device:
+                            xb = xb.cpu().numpy()
                     elif pool is not None:
                         xb = np.stack(list(pool.map(lambda ip: apply_pixels_host(ip[0], ip[1], self.input_size), zip(raw, prm))))
                     else:

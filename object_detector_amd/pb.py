@@ -102,6 +102,13 @@ class PriorBoxes:
             return y, npos, assigned
         return y.cpu().numpy(), npos.cpu().numpy(), assigned.cpu().numpy()
 
+    def encode_truth_device(self, y):
+        """encode_truth whose result stays on the device: list of annotations -> f32 DEVICE tensor [B,P,C] (the generator
+        callback for training loops: `Trainer.step(x, y_target=...)` takes it as is)."""
+        if isinstance(y, ObjectsAnnotation):
+            y = [y]
+        return self.encode_batch(list(y), return_device=True)[0]
+
     def encode_truth(self, y):
         """Generator callback (check_assign.py:21): list of annotations -> array [B,P,C]; one annotation -> [P,C]."""
         if isinstance(y, ObjectsAnnotation):

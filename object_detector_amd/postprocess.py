@@ -39,6 +39,9 @@ class Postprocessor:
         self.keep_count = torch.empty((B,), dtype=torch.int32, device=dev)
         self.ws_topk_bytes = self.lib.od_topk_workspace_bytes(B, P * NC, K)
         self.ws_nms_bytes = self.lib.od_nms_workspace_bytes(B, K)
+        # kept detections of the batch as one record block + its pinned host mirror: ONE device->host copy per batch
+        self.det = torch.empty((B, 1 + 6 * self.max_det), dtype=torch.float32, device=dev)
+        self.det_host = torch.empty((B, 1 + 6 * self.max_det), dtype=torch.float32).pin_memory()
         self.ws_topk = torch.empty((self.ws_topk_bytes,), dtype=torch.uint8, device=dev)
         self.ws_nms = torch.empty((self.ws_nms_bytes,), dtype=torch.uint8, device=dev)
 
@@ -62,6 +65,26 @@ class Postprocessor:
                                    self.keep_flat.data_ptr(), self.keep_count.data_ptr(), self.ws_nms.data_ptr(),
                                    self.ws_nms_bytes, _stream_ptr()), "od_nms")
         return self.keep_flat, self.keep_count
+
+    def gather(self):
+        """Queue the gather of this batch's kept detections (od_gather_detections) and its copy into the pinned host block
+        on the current stream; read with detections_host() after the stream / event has been waited for."""
+        _lib.check(self.lib.od_gather_detections(self.ctx.handle, self.conf.data_ptr(), self.boxes.data_ptr(),
+                                                 self.keep_flat.data_ptr(), self.keep_count.data_ptr(), self.B, self.P,
+                                                 self.NC, self.max_det, self.det.data_ptr(), _stream_ptr()),
+                   "od_gather_detections")
+        self.det_host.copy_(self.det, non_blocking=True)
+
+    def detections_host(self, n_valid):
+        """-> [(flat i32 [n], conf f32 [n], boxes f32 [n,4])] for the first n_valid images, from the pinned block."""
+        import numpy as np
+        a = self.det_host.numpy()
+        out = []
+        for b in range(n_valid):
+            n = int(a[b, :1].view(np.int32)[0])
+            rows = a[b, 1:1 + 6 * n].reshape(n, 6)
+            out.append((rows[:, 0].copy().view(np.int32), rows[:, 1].copy(), rows[:, 2:6].copy()))
+        return out
 
     def run(self, pred: torch.Tensor, conf_threshold: float):
         """pred [B,P,C] -> (keep_flat i32 [B,max_det] (-1 padded), keep_count i32 [B]); conf/boxes stay on device."""

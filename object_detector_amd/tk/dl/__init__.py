@@ -1,19 +1,49 @@
 """tk.dl: session() scope (reference voc_validate.py:17) and the `od` sub-namespace."""
 import contextlib
+import os
 
 from . import od  # noqa: F401
 
 
+def dist_env():
+    """(rank, local_rank, world) as the launcher (torch.distributed.run / torchrun) exported them; (0, 0, 1) when alone."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def is_main_process():
+    """True on the rank that writes files (logs, result images): rank 0, or a process that is not part of a job."""
+    import torch
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return torch.distributed.get_rank() == 0
+    return dist_env()[0] == 0
+
+
 @contextlib.contextmanager
 def session(device=None):
-    """The reference opens a TF session here; on MI355X it pins the process to its GPU and drains it on exit."""
-    import os
-
+    """The reference opens a TF session here (and `use_multi_gpu=True` replicates the model inside it,
+    voc_validate.py:17,26).  On MI355X the unit is one process per GPU: when the launcher started several ranks
+    (WORLD_SIZE > 1) and no process group exists yet, this scope creates it BEFORE the first GPU call -- backend "nccl"
+    (= RCCL over xGMI) bound to this rank's GPU, or $OD_DIST_BACKEND / $OD_BENCH_BACKEND (e.g. "gloo" to rehearse several
+    ranks on one GPU or on CPUs) -- pins the process to its GPU, and on exit drains the GPU and destroys the group it
+    created.  `ObjectDetector(use_multi_gpu=True).predict` then shards the images over the ranks (detector.dist_info)."""
     import torch
-    if torch.cuda.is_available():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) if device is None else device)
+    rank, local_rank, world = dist_env()
+    created = False
+    ndev = torch.cuda.device_count()  # does not initialise the GPU runtime
+    if world > 1 and torch.distributed.is_available() and not torch.distributed.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC; must be set before the runtime comes up
+        backend = os.environ.get("OD_DIST_BACKEND") or os.environ.get("OD_BENCH_BACKEND") or ("nccl" if ndev > 0 else "gloo")
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank % ndev}"))
+        else:
+            torch.distributed.init_process_group(backend)
+        created = True
+    if ndev > 0 and torch.cuda.is_available():
+        torch.cuda.set_device((local_rank % ndev) if device is None else device)
     try:
         yield
     finally:
-        if torch.cuda.is_available():
+        if ndev > 0 and torch.cuda.is_available():
             torch.cuda.synchronize()
+        if created:
+            torch.distributed.destroy_process_group()

@@ -8,6 +8,11 @@ _ROOT = "od"
 
 
 def init(path=None, level=logging.INFO):
+    """Console handler on every rank; the FILE only on the main process (rank 0): in a multi-rank job every rank runs the
+    same script, and N ranks opening the same log with mode "w" would truncate each other."""
+    from .dl import is_main_process
+    if not is_main_process():
+        path = None
     logger = logging.getLogger(_ROOT)
     logger.setLevel(level)
     logger.handlers.clear()

@@ -41,7 +41,7 @@ class _Node:
 class Trainer:
     def __init__(self, params, batch_size, input_size=(320, 320), device="cuda:0", lr=1e-3, momentum=0.9,
                  weight_decay=0.0, loss_scale=1024.0, box_mode="smooth_l1", backbone_act=("leaky", 0.1),
-                 head_act=("elu", 1.0), comm=None, world_size=1):
+                 head_act=("elu", 1.0), comm=None, world_size=1, grad_payload=None, dynamic_loss_scale=True):
         self.ctx = Context.get(device)
         self.lib = self.ctx.lib
         self.device = torch.device(device)
@@ -52,6 +52,17 @@ class Trainer:
         self.lr, self.momentum, self.weight_decay = float(lr), float(momentum), float(weight_decay)
         self.loss_scale, self.box_mode = float(loss_scale), box_mode
         self.comm, self.world = comm, int(world_size)
+        # gradient all-reduce payload: "f32" (exact sum) or "bf16" (BASELINE.json configs[4]: half the xGMI bytes; each rank's
+        # f32 gradients are rounded to bf16, summed by RCCL in bf16, widened back to f32 before the optimizer)
+        self.grad_payload = grad_payload or os.environ.get("OD_TRAIN_GRAD_PAYLOAD", "f32")
+        if self.grad_payload not in ("f32", "bf16"):
+            raise ValueError(f"grad_payload must be 'f32' or 'bf16', got {self.grad_payload!r}")
+        # loss-scale guard: a non-finite value in the flat gradient buffer (one f16 overflow in a loss-scaled dz is enough)
+        # makes the device skip the update; the host learns about it one step later and halves the scale
+        self.dynamic_loss_scale = bool(dynamic_loss_scale)
+        self.skipped_steps = 0
+        self._good_steps = 0
+        self.loss_scale_growth_interval = 2000
         self.pb = PriorBoxes((self.H0, self.W0), self.num_classes, device=self.device)
         self.P = len(self.pb)
         dev = self.device
@@ -112,7 +123,14 @@ class Trainer:
         # each all-reduced on its own stream as soon as its last layer is final -> the RCCL traffic overlaps the rest of
         # the backward pass.  OD_TRAIN_BUCKET_MB=0 -> one all-reduce after backward.
         self.bucket_mb = float(os.environ.get("OD_TRAIN_BUCKET_MB", "32"))
-        self.cstream = torch.cuda.Stream(device=dev) if (self.comm is not None and self.bucket_mb > 0) else None
+        # with an RCCL communicator (comm) the collectives go through od_allreduce; without one but world_size > 1 they go
+        # through torch.distributed's default group (gloo rehearsals on one GPU, CPU-side tests) -- same buckets, same streams
+        self.cstream = torch.cuda.Stream(device=dev) if ((self.comm is not None or self.world > 1) and self.bucket_mb > 0) else None
+        self.payload_buf = (torch.empty(self.n_flat, dtype=torch.bfloat16, device=dev) if self.grad_payload == "bf16"
+                            else None)
+        self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._nonfinite_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._nonfinite_ev = None
         self._buckets = self._make_buckets(int(self.bucket_mb * (1 << 20) / 4)) if self.cstream is not None else []
         self._next_bucket = 0
         mxc = max(self.lib.od_bn_workspace_bytes(self.B * (n.H // n.stride) * (n.W // n.stride), n.Cout) + 2 * n.Cout * 4
@@ -136,9 +154,26 @@ class Trainer:
             self.cstream.wait_stream(main)  # BatchNorm / bias gradients of these layers
             if self.wstream is not None:
                 self.cstream.wait_stream(self.wstream)  # their weight gradients (slab reduce)
-            _lib.check(self.lib.od_allreduce(self.comm, self.grads.data_ptr() + 4 * lo, hi - lo, _lib.OD_DT_F32,
-                                             C.c_void_p(self.cstream.cuda_stream)), "od_allreduce(bucket)")
+            with torch.cuda.stream(self.cstream):
+                self._reduce_range(lo, hi)
             self._next_bucket += 1
+
+    def _reduce_range(self, lo, hi):
+        """Sum grads[lo:hi] over the data-parallel ranks on the CURRENT stream, in the configured payload type."""
+        lib, h, s = self.lib, self.ctx.handle, _stream_ptr()
+        g = self.grads[lo:hi]
+        if self.grad_payload == "bf16":
+            pb = self.payload_buf[lo:hi]
+            _lib.check(lib.od_cast_f32_bf16(h, g.data_ptr(), pb.data_ptr(), hi - lo, s), "od_cast_f32_bf16")
+            if self.comm is not None:
+                _lib.check(lib.od_allreduce(self.comm, pb.data_ptr(), hi - lo, _lib.OD_DT_BF16, s), "od_allreduce(bf16)")
+            else:
+                dp_allreduce_(pb)
+            _lib.check(lib.od_cast_bf16_f32(h, pb.data_ptr(), g.data_ptr(), hi - lo, s), "od_cast_bf16_f32")
+        elif self.comm is not None:
+            _lib.check(lib.od_allreduce(self.comm, g.data_ptr(), hi - lo, _lib.OD_DT_F32, s), "od_allreduce")
+        else:
+            dp_allreduce_(g)
 
     def view(self, buf, name, kind):
         o, n = self.seg[(name, kind)]
@@ -431,18 +466,17 @@ class Trainer:
             assert self._next_bucket == len(self._buckets), "a gradient bucket was never launched"
             torch.cuda.current_stream(self.device).wait_stream(self.cstream)
             return
-        if self.world <= 1:
+        if self.world <= 1 and self.comm is None:
             return
-        if self.comm is not None:
-            _lib.check(self.lib.od_allreduce(self.comm, self.grads.data_ptr(), self.n_flat, _lib.OD_DT_F32, _stream_ptr()),
-                       "od_allreduce")
-        else:
-            dp_allreduce_(self.grads)
+        self._reduce_range(0, self.n_flat)
 
     def sgd(self):
         """One multi-tensor launch over the flat parameter buffer (per-segment LR multipliers of docs/MODEL.md:84-90 and
         weight decay in a device table), one multi-layer re-pack launch."""
         inv = dp_effective_scale(self.loss_scale, self.world)  # grads are averaged over ranks
+        # after the all-reduce, so every rank sees the same flag: Inf / NaN anywhere -> this step's update is skipped
+        _lib.check(self.lib.od_grad_nonfinite(self.ctx.handle, self.grads.data_ptr(), self.n_flat, self.nonfinite.data_ptr(),
+                                              _stream_ptr()), "od_grad_nonfinite")
         key = (self.lr, self.weight_decay)
         if getattr(self, "_sgd_key", None) != key:
             segs = []
@@ -455,8 +489,30 @@ class Trainer:
             self._sgd_table, self._sgd_n, self._sgd_key = self._device_table(segs), len(segs), key
         _lib.check(self.lib.od_sgd_step_multi(self.ctx.handle, self.params.data_ptr(), self.mom.data_ptr(),
                                               self.grads.data_ptr(), self._sgd_table.data_ptr(), self._sgd_n,
-                                              self.momentum, inv, _stream_ptr()), "od_sgd_step_multi")
-        self._repack()
+                                              self.momentum, inv, self.nonfinite.data_ptr(), _stream_ptr()),
+                   "od_sgd_step_multi")
+        self._repack()  # (a skipped step re-packs unchanged masters: harmless, and keeps the launch sequence fixed)
+        self._nonfinite_host.copy_(self.nonfinite, non_blocking=True)
+        self._nonfinite_ev = torch.cuda.Event()
+        self._nonfinite_ev.record()
+
+    def _poll_nonfinite(self):
+        """The previous step's flag (its copy finished long ago: no stall).  A skipped step halves the loss scale; a long
+        clean run doubles it again.  BatchNorm running statistics were already updated by the skipped step's forward --
+        they are a moving average of finite activations and stay valid."""
+        if self._nonfinite_ev is None:
+            return
+        self._nonfinite_ev.synchronize()
+        self._nonfinite_ev = None
+        if int(self._nonfinite_host[0]) != 0:
+            self.skipped_steps += 1
+            self._good_steps = 0
+            if self.dynamic_loss_scale:
+                self.loss_scale = max(1.0, self.loss_scale * 0.5)
+        else:
+            self._good_steps += 1
+            if self.dynamic_loss_scale and self._good_steps >= self.loss_scale_growth_interval:
+                self.loss_scale, self._good_steps = min(self.loss_scale * 2.0, 65536.0), 0
 
     def sgd_per_tensor(self):
         inv = dp_effective_scale(self.loss_scale, self.world)  # grads are averaged over ranks
@@ -470,6 +526,7 @@ class Trainer:
 
     def step(self, x_u8, annotations=None, y_target=None):
         """One training step.  annotations: list[ObjectsAnnotation] (encoded on the device) or y_target [B,P,C]."""
+        self._poll_nonfinite()
         if y_target is None:
             y_target, _npos, _ = self.pb.encode_batch(annotations, return_device=True)
         self.forward(x_u8)

@@ -1,0 +1,111 @@
+"""The real data-parallel path with N > 1 ranks, on the one GPU the test box has (reference knob
+use_multi_gpu=True, check_assign.py:19 / voc_validate.py:26): two fresh child processes on cuda:0, gloo collectives, each
+running `Trainer.step` on its half of a global batch with the BUCKETED, OVERLAPPED all-reduce enabled (buckets routed through
+torch.distributed when there is no RCCL communicator).  On an 8-GPU node the same code runs with backend nccl = RCCL."""
+import os
+import pathlib
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def _launch(world, port, args, cwd=None, script=None, extra_env=None):
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, str(script or ROOT / "tests" / "dp_worker.py")] + list(args), env=env,
+                                      cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    bad = [f"--- rank {r} (rc {p.returncode}) ---\n{o[-2500:]}" for r, (p, o) in enumerate(zip(procs, outs)) if p.returncode != 0]
+    assert not bad, "\n".join(bad)
+    return outs
+
+
+@pytest.fixture(scope="module")
+def sequential_shards(cuda):
+    """The two shards' gradients computed one after the other in THIS process (world 1, no exchange)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import dp_worker as D
+    from object_detector_amd import weights as W
+    from object_detector_amd.trainer import Trainer
+    x, anns = D.make_batch(D.GLOBAL_B, D.S)
+    per = D.GLOBAL_B // 2
+    gs = []
+    for r in range(2):
+        tr = Trainer(W.random_init(2), per, (D.S, D.S), device=cuda, lr=D.LR, momentum=0.9, loss_scale=D.LS)
+        y, _n, _ = tr.pb.encode_batch(anns[r * per:(r + 1) * per], return_device=True)
+        tr.forward(torch.from_numpy(x[r * per:(r + 1) * per]).to(cuda))
+        tr.loss(y)
+        gs.append(tr.backward().cpu().numpy().copy())
+        seg = dict(tr.seg)
+        params0 = tr.params.cpu().numpy().copy()
+    return gs, seg, params0, D
+
+
+def test_two_ranks_bucketed_allreduce_equals_sum_of_shards(cuda, sequential_shards, tmp_path):
+    (g0, g1), seg, params0, D = sequential_shards
+    _launch(2, 29811, [str(tmp_path), "f32", "8"])
+    r0 = np.load(tmp_path / "rank0_f32_8.npz")
+    r1 = np.load(tmp_path / "rank1_f32_8.npz")
+    assert int(r0["nbuckets"]) >= 4
+    # both ranks end the step with bit-identical gradients, momentum and parameters
+    for k in ("grads", "mom", "params"):
+        assert np.array_equal(r0[k], r1[k]), k
+    # and the exchanged gradient is the f32 sum of the two shards' gradients (one addition per element: order-free);
+    # the first layer's weight gradient is accumulated with f32 atomics inside each rank (order noise)
+    o0, n0 = seg[("b.conv0", "w")]
+    mask = np.ones(g0.size, bool)
+    mask[o0:o0 + n0] = False
+    want = g0 + g1
+    assert np.array_equal(r0["grads"][mask], want[mask])
+    np.testing.assert_allclose(r0["grads"][o0:o0 + n0], want[o0:o0 + n0], rtol=1e-4, atol=1e-3)
+    # the optimizer averaged over the ranks: w1 = w0 - lr_seg * (sum / (loss_scale * world))   (momentum buffer was zero)
+    from object_detector_amd.trainer import lr_multiplier
+    for (name, kind), (o, n) in list(seg.items())[::17]:
+        step = D.LR * lr_multiplier(name) * want[o:o + n] / (D.LS * 2)
+        np.testing.assert_allclose(r0["params"][o:o + n], params0[o:o + n] - step, rtol=1e-5, atol=1e-7)
+    # one collective after backward instead of overlapped buckets: same numbers
+    _launch(2, 29813, [str(tmp_path), "f32", "0"])
+    assert np.array_equal(np.load(tmp_path / "rank0_f32_0.npz")["grads"][mask], r0["grads"][mask])
+
+
+def test_two_ranks_bf16_payload_cost(cuda, sequential_shards, tmp_path):
+    """BASELINE.json configs[4]: bf16 gradient payload.  Its accuracy cost against the f32 payload, per parameter segment."""
+    (g0, g1), seg, _p0, D = sequential_shards
+    _launch(2, 29815, [str(tmp_path), "bf16", "8"])
+    r0 = np.load(tmp_path / "rank0_bf16_8.npz")
+    r1 = np.load(tmp_path / "rank1_bf16_8.npz")
+    assert np.array_equal(r0["grads"], r1["grads"]) and np.array_equal(r0["params"], r1["params"])
+    want = (g0 + g1).astype(np.float64)
+    rel = {}
+    for (name, kind), (o, n) in seg.items():
+        rel[f"{name}.{kind}"] = float(np.linalg.norm(r0["grads"][o:o + n] - want[o:o + n]) / max(np.linalg.norm(want[o:o + n]), 1e-30))
+    worst = sorted(rel.items(), key=lambda kv: -kv[1])[:4]
+    print("bf16 payload vs f32 payload, relative L2 per segment: worst", worst, "median", float(np.median(list(rel.values()))))
+    # two roundings to bf16 (8-bit mantissa: 2^-9 relative each) + one bf16 sum
+    assert worst[0][1] < 6e-3 and np.median(list(rel.values())) < 4e-3
+    # every value the ranks hold is a bf16 number widened to f32
+    assert (r0["grads"].view(np.uint32) & 0xFFFF == 0).all()
+
+
+def test_voc_validate_two_ranks(cuda, tmp_path):
+    """scripts/voc_validate.py under a 2-rank launch (use_multi_gpu=True did nothing in the entry points): the
+    ranks shard the images, ONE validate.log is written, and its mAP line equals the single-process run's."""
+    args = ["--synthetic", "6", "--batch-size", "2", "--input-size", "96", "96"]
+    one = tmp_path / "one"
+    two = tmp_path / "two"
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "voc_validate.py"), "--result-dir", str(one)] + args,
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    _launch(2, 29817, ["--result-dir", str(two)] + args, cwd=str(tmp_path), script=ROOT / "scripts" / "voc_validate.py",
+            extra_env={"OD_DIST_BACKEND": "gloo"})
+    get = lambda p: [ln.split("] ", 1)[1] for ln in (p / "validate.log").read_text().splitlines() if "mAP=" in ln]
+    assert len(get(two)) == 1 and get(two) == get(one), (get(one), get(two))

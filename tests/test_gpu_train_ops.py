@@ -133,3 +133,32 @@ def test_generator_device_path(cuda, tmp_path):
         for yy in yb:
             obj = yy[:, 1] == 1
             assert obj.sum() >= 1 and (np.argmax(yy[obj, 2:-4], -1) < 3).all()
+
+
+def test_generator_feeds_trainer_without_leaving_the_device(cuda):
+    """SURVEY.md §8f rank 3 (reference check_generator.py:17-22, docs/MODEL.md:60-64): with on_device=True the generator's
+    batches are uint8 DEVICE tensors and encode_truth_device keeps the targets on the device, so a training step consumes
+    them as they are -- the pixels and targets never visit the host.  Same seed => same pixels / targets as the numpy path."""
+    import torch
+    from object_detector_amd import od_gen, weights as W
+    from object_detector_amd.pb import ObjectsAnnotation
+    from object_detector_amd.trainer import Trainer
+    rng = np.random.default_rng(0)
+    S, B = 96, 2
+    X = np.array([rng.integers(0, 256, (120, 200, 3), dtype=np.uint8) for _ in range(4)], dtype=object)
+    y = np.array([ObjectsAnnotation(None, 200, 120, [i], [[0.2, 0.2, 0.7, 0.8]]) for i in range(4)], dtype=object)
+    tr = Trainer(W.random_init(2), B, (S, S), device=cuda, lr=0.01, momentum=0.0, loss_scale=256.0)
+    gen = od_gen.create_generator((S, S), preprocess_input=None, encode_truth=tr.pb.encode_truth_device, device=cuda,
+                                  on_device=True)
+    host = od_gen.create_generator((S, S), preprocess_input=None, encode_truth=tr.pb.encode_truth, device=cuda)
+    g, steps = gen.flow(X, y, batch_size=B, data_augmentation=True, seed=3)
+    gh, _ = host.flow(X, y, batch_size=B, data_augmentation=True, seed=3)
+    losses = []
+    for _i, (xb, yb), (xh, yh) in zip(range(4), g, gh):
+        assert isinstance(xb, torch.Tensor) and xb.is_cuda and xb.dtype == torch.uint8 and tuple(xb.shape) == (B, S, S, 3)
+        assert isinstance(yb, torch.Tensor) and yb.is_cuda and tuple(yb.shape) == (B, tr.P, 26)
+        assert np.array_equal(xb.cpu().numpy(), xh) and np.array_equal(yb.cpu().numpy(), yh)
+        losses.append(float(tr.step(xb, y_target=yb)[3]))
+    assert all(np.isfinite(losses)) and tr.skipped_steps == 0
+    with pytest.raises(ValueError):
+        od_gen.create_generator((S, S), on_device=True)

@@ -165,3 +165,66 @@ def test_bucketed_allreduce_overlapped_with_backward(cuda, monkeypatch):
     assert torch.equal(tr.grads[mask], ref.grads[mask]) and torch.equal(tr.params[mask], ref.params[mask])
     torch.testing.assert_close(tr.grads[o0:o0 + n0], ref.grads[o0:o0 + n0], rtol=1e-4, atol=1e-3)
     _lib.check(ctx.lib.od_comm_destroy(h))
+
+
+def test_nonfinite_gradient_skips_update_and_halves_loss_scale(cuda):
+    """one f16 overflow in a loss-scaled dz used to put Inf/NaN into the master weights for good.  Now the flat
+    gradient buffer is checked on the device after the all-reduce (od_grad_nonfinite) and od_sgd_step_multi leaves weights
+    and momentum untouched; the host halves the loss scale when it sees the flag one step later."""
+    from object_detector_amd.trainer import Trainer
+    B, S = 2, 96
+    params, x, anns = _setup(cuda, B, S)
+    tr = Trainer(params, B, (S, S), device=cuda, lr=0.01, momentum=0.9, loss_scale=256.0)
+    xt = torch.from_numpy(x).to(cuda)
+    tr.step(xt, anns)  # a clean step first: momentum is non-zero afterwards
+    torch.cuda.synchronize()
+    assert int(tr.nonfinite.item()) == 0
+    p0, m0 = tr.params.clone(), tr.mom.clone()
+    wf0 = {k: v.clone() for k, v in tr.wf.items()}
+    y, _n, _ = tr.pb.encode_batch(anns, return_device=True)
+    tr._poll_nonfinite()
+    tr.forward(xt)
+    tr.loss(y)
+    tr.grad_pred[0, 5, 3] = float("inf")  # what an overflowing loss gradient looks like
+    tr.backward()
+    tr.allreduce()
+    tr.sgd()
+    torch.cuda.synchronize()
+    assert int(tr.nonfinite.item()) == 1 and not bool(torch.isfinite(tr.grads).all())
+    assert torch.equal(tr.params, p0) and torch.equal(tr.mom, m0)
+    assert all(torch.equal(tr.wf[k], wf0[k]) for k in wf0)
+    assert tr.skipped_steps == 0 and tr.loss_scale == 256.0
+    tr.step(xt, anns)  # the next step learns about it (no stall: the flag was copied asynchronously) and runs clean
+    torch.cuda.synchronize()
+    assert tr.skipped_steps == 1 and tr.loss_scale == 128.0
+    assert int(tr.nonfinite.item()) == 0 and bool(torch.isfinite(tr.params).all()) and not torch.equal(tr.params, p0)
+    # NaN is caught as well, anywhere in the buffer (tail elements included)
+    g = torch.zeros(1003, device=cuda)
+    flag = torch.zeros(1, dtype=torch.int32, device=cuda)
+    from object_detector_amd import _lib
+    from object_detector_amd.net import _stream_ptr
+    for pos in (None, 0, 511, 1000, 1002):
+        g.zero_()
+        if pos is not None:
+            g[pos] = float("nan") if pos % 2 else float("-inf")
+        _lib.check(tr.lib.od_grad_nonfinite(tr.ctx.handle, g.data_ptr(), g.numel(), flag.data_ptr(), _stream_ptr()))
+        assert int(flag.item()) == int(pos is not None), pos
+
+
+def test_bf16_casts_round_to_nearest_even(cuda):
+    from object_detector_amd import _lib
+    from object_detector_amd.net import Context, _stream_ptr
+    ctx = Context.get(cuda)
+    rng = np.random.default_rng(0)
+    v = np.concatenate([rng.normal(0, 1, 100000), rng.normal(0, 1e-30, 1000), rng.normal(0, 1e30, 1000),
+                        [0.0, -0.0, np.inf, -np.inf, np.nan, 1.00390625, 1.01171875, 3.3895314e38]]).astype(np.float32)
+    src = torch.from_numpy(v).to(cuda)
+    dst = torch.empty(v.size, dtype=torch.bfloat16, device=cuda)
+    _lib.check(ctx.lib.od_cast_f32_bf16(ctx.handle, src.data_ptr(), dst.data_ptr(), v.size, _stream_ptr()))
+    want = src.to(torch.bfloat16)
+    assert torch.equal(dst.view(torch.int16)[:-4], want.view(torch.int16)[:-4])
+    assert torch.equal(torch.isnan(dst), torch.isnan(want)) and torch.equal(dst[~torch.isnan(dst)], want[~torch.isnan(want)])
+    back = torch.empty(v.size, dtype=torch.float32, device=cuda)
+    _lib.check(ctx.lib.od_cast_bf16_f32(ctx.handle, dst.data_ptr(), back.data_ptr(), v.size, _stream_ptr()))
+    ok = ~torch.isnan(back)
+    assert torch.equal(back[ok], want.float()[ok])

@@ -9,10 +9,28 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def _worker(rank, world, port, n, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
+def _worker(rank, world, port, n, q, tmp):
+    """The script-level path of scripts/voc_validate.py / voc_evaluate.py: `with tk.dl.session(): tk.log.init(file)` then
+    predict.  session() must create the process group from the launcher's environment (nothing else in the scripts
+    does), the log FILE and result images must be written by rank 0 only, and the group must be gone afterwards."""
+    import pathlib
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), OD_DIST_BACKEND="gloo")
+    import pytoolkit as tk
+    tmp = pathlib.Path(tmp)
+    assert not dist.is_initialized()
+    with tk.dl.session():
+        assert dist.is_initialized() and dist.get_world_size() == world and dist.get_rank() == rank
+        assert tk.dl.is_main_process() == (rank == 0)
+        tk.log.init(tmp / "validate.log")
+        tk.log.get("t").info("rank %d reporting", rank)
+        tk.ndimage.save(tmp / "img" / "a.jpg", np.full((8, 8, 3), 10 + rank, np.uint8))
+        _sharded_predict(rank, world, n, q)
+    assert not dist.is_initialized()  # the scope destroys the group it created
+
+
+def _sharded_predict(rank, world, n, q):
+    if True:
         from object_detector_amd.detector import ObjectsPrediction, dist_info, gather_results, shard_indices
         assert dist_info(True) == (rank, world) and dist_info(False) == (0, 1)
         mine = shard_indices(n, rank, world)
@@ -22,15 +40,13 @@ def _worker(rank, world, port, n, q):
         assert sorted(allr) == list(range(n))
         ok = all((allr[i].bboxes == i).all() and len(allr[i]) == i % 3 for i in range(n))
         q.put((rank, mine, ok))
-    finally:
-        dist.destroy_process_group()
 
 
-def test_sharded_predict_world2():
+def test_sharded_predict_world2(tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     n, world, port = 11, 2, 29731
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q, str(tmp_path))) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
@@ -42,6 +58,11 @@ def test_sharded_predict_world2():
     assert all(r[2] for r in res)
     # every image is processed exactly once
     assert sorted(res[0][1] + res[1][1]) == list(range(n))
+    # one log file, written by rank 0 alone; one result image, rank 0's
+    log = (tmp_path / "validate.log").read_text()
+    assert "rank 0 reporting" in log and "rank 1 reporting" not in log
+    from PIL import Image
+    assert np.asarray(Image.open(tmp_path / "img" / "a.jpg"))[0, 0, 0] in (9, 10, 11)  # rank 0 wrote 10 (JPEG rounding)
 
 
 def _dp_worker(rank, world, port, q):
