@@ -206,12 +206,204 @@ __global__ __launch_bounds__(256, 2) void od_conv_wgrad(WgradKP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 8-wave form: 256 output channels x 256 (tap, ci) columns per workgroup, one workgroup per CU.
+// The 128 x 128 kernel above moves 16 KiB L2 -> LDS per 1.05 MFLOP (4 LDS-DMA issues per wave per 16 MFMAs: the waves are
+// DMA-issue bound, 0.1 of the MFMA peak in the training step); the 256-wide tile halves the bytes per flop and gives
+// every wave 32 MFMAs per 4 DMA issues and per barrier.  LDS image: per stage four half-tiles of [32 pixels][128 channels]
+// (dZ channels 0-127 / 128-255, X columns 0-127 / 128-255), each with the row layout / swizzle of the kernel above, so the
+// transposed fragment reads stay conflict-free.  Wave (wr, wc) = (wave >> 1, wave & 1) owns 64 channels x 128 columns.
+// The MFMA takes the X fragment as its first operand: a lane then holds 4 CONSECUTIVE columns of one output channel, and
+// the f32 partial tile leaves as 16-byte stores (32 per wave) instead of 128 scalar ones.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int W8_TILE = 256;
+constexpr int W8_NSTAGE = 4;
+constexpr int W8_STAGE_BYTES = 4 * OPER_BYTES;  // 32 KiB
+constexpr int W8_LDS = W8_NSTAGE * W8_STAGE_BYTES;  // 128 KiB
+
+__global__ __launch_bounds__(512, 2) void od_conv_wgrad_w8(WgradKP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem8[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  int bid = blockIdx.x;
+  const int sp = bid % p.split;
+  bid /= p.split;
+  const int ct = bid % p.ctiles, rt = bid / p.ctiles;
+  const int co0 = rt * W8_TILE, n0 = ct * W8_TILE;
+  const int chunk0 = sp * p.chunks_per_split;
+  const int nchunks_total = (p.M + KC - 1) / KC;
+  const int nch = min(p.chunks_per_split, nchunks_total - chunk0);
+  if (nch <= 0) return;
+
+  // ---- DMA mapping: wave w fills rows 4w .. 4w+3 of each of the four half-tiles (one 1-KiB instruction each)
+  const int prow = 4 * wave + (lane >> 4);
+  const int lchunk = (lane & 15) ^ swz_key(prow);
+  int xtap_dy[2], xtap_dx[2], xci[2];
+  bool xcol_ok[2], dcol_ok[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int j = n0 + h * 128 + lchunk * 8;
+    const int tap = j / p.Cin;
+    xci[h] = j - tap * p.Cin;
+    xtap_dy[h] = tap / p.ks;
+    xtap_dx[h] = tap - xtap_dy[h] * p.ks;
+    xcol_ok[h] = j < p.Ktot;
+    dcol_ok[h] = (co0 + h * 128 + lchunk * 8) < p.Cout;
+  }
+  int sm = chunk0 * KC + prow, sb, sho, swo;
+  {
+    const unsigned b = (unsigned)sm / (unsigned)p.HoWo;
+    const unsigned pix = (unsigned)sm - b * (unsigned)p.HoWo;
+    sb = (int)b;
+    sho = (int)(pix / (unsigned)p.Wo);
+    swo = (int)(pix - (unsigned)sho * (unsigned)p.Wo);
+  }
+  auto stage = [&](int buf) {  // stages are issued strictly in chunk order
+    char* base = smem8 + buf * W8_STAGE_BYTES + wave * 1024;
+    const bool mok = sm < p.M;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f16* dsrc = (mok && dcol_ok[h]) ? p.dz + ((long long)sm * p.Cout + co0 + h * 128 + lchunk * 8) : p.zero;
+      glds16(dsrc, base + h * OPER_BYTES);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int hi = sho * p.stride + xtap_dy[h] - p.pad, wi = swo * p.stride + xtap_dx[h] - p.pad;
+      const bool xok = mok && xcol_ok[h] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      const f16* xsrc = xok ? p.x + ((((long long)sb * p.H + hi) * p.W + wi) * p.Cin + xci[h]) : p.zero;
+      glds16(xsrc, base + (2 + h) * OPER_BYTES);
+    }
+    sm += KC;
+    swo += KC;
+    while (swo >= p.Wo) {
+      swo -= p.Wo;
+      if (++sho == p.Ho) {
+        sho = 0;
+        ++sb;
+      }
+    }
+  };
+
+  // ---- MFMA side ---------------------------------------------------------------------------------------------------
+  const int wr = wave >> 1, wc = wave & 1;
+  const int d_half = wr >> 1, d_ch0 = (wr & 1) * 64;
+  f32x4 acc[8][4];  // [x fragment j][dz fragment i]: element e = column j*16 + lq*4 + e, channel i*16 + l15
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int tq = l15 >> 2, tp = l15 & 3;
+  int roff[2], rkey[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = 8 * lq + 4 * h + tq;
+    roff[h] = r * ROWB;
+    rkey[h] = swz_key(r);
+  }
+  auto frag = [&](const char* tile, int ch) -> f16x8 {  // 16 channels starting at `ch` of a half-tile, this lane's 8 pixels
+    const int u = ch / 4 + tp;
+    h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+        (__attribute__((address_space(3))) h4*)(tile + roff[0] + (((u >> 1) ^ rkey[0]) * 16) + (u & 1) * 8));
+    h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+        (__attribute__((address_space(3))) h4*)(tile + roff[1] + (((u >> 1) ^ rkey[1]) * 16) + (u & 1) * 8));
+    f16x8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f[e] = (f16)lo[e];
+      f[4 + e] = (f16)hi[e];
+    }
+    return f;
+  };
+
+#pragma unroll
+  for (int s0 = 0; s0 < W8_NSTAGE - 1; ++s0)
+    if (s0 < nch) stage(s0);
+  int buf = 0, sbuf = W8_NSTAGE - 1;
+  for (int c = 0; c < nch; ++c, buf = (buf + 1 == W8_NSTAGE ? 0 : buf + 1)) {
+    // 4 DMAs per chunk per wave; chunks c+1, c+2 may stay in flight
+    if (c + 2 < nch) {
+      wait_vmcnt<8>();
+    } else if (c + 1 < nch) {
+      wait_vmcnt<4>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();  // every wave's rows of chunk c have landed; chunk c-1's buffer is free
+    if (c + W8_NSTAGE - 1 < nch) {
+      stage(sbuf);
+      sbuf = sbuf + 1 == W8_NSTAGE ? 0 : sbuf + 1;
+    }
+    const char* st = smem8 + buf * W8_STAGE_BYTES;
+    const char* dtile = st + d_half * OPER_BYTES;
+    const char* xtile = st + (2 + wc) * OPER_BYTES;
+    f16x8 df[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) df[i] = frag(dtile, d_ch0 + i * 16);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f16x8 xf = frag(xtile, j * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, df[i], acc[j][i], 0, 0, 0);
+    }
+  }
+
+  // ---- f32 partial tile -> slab (16-byte stores: 4 consecutive columns per lane) or atomic adds into dW
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int co = co0 + wr * 64 + i * 16 + l15;
+    if (co >= p.Cout) continue;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = n0 + wc * 128 + j * 16 + lq * 4;
+      if (col >= p.Ktot) continue;  // Ktot is a multiple of 8: a group of 4 columns is all in or all out
+      if (p.slabs) {
+        *(f32x4*)(p.slabs + ((long long)sp * p.Cout + co) * p.Kstride + col) = acc[j][i];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(p.dw + (long long)co * p.Kstride + col + e, acc[j][i][e]);
+      }
+    }
+  }
+}
+
 }  // namespace
 
+// pixel split of the 256-wide kernel: one 512-thread workgroup per CU, one round (tiles x split <= CUs), and at least 12
+// chunks per workgroup so that the pipeline fill and the 256-KiB partial-tile store stay a small part of it
+static int wgrad_w8_split(int cus, int nchunks, int Cout, int Ktot, int* chunks_per_split) {
+  const int tiles = od_ceil_div(Cout, W8_TILE) * od_ceil_div(Ktot, W8_TILE);
+  int split = cus / tiles;
+  if (split < 1) split = 1;
+  if (split > nchunks / 12) split = nchunks / 12 > 0 ? nchunks / 12 : 1;
+  const int cps = od_ceil_div(nchunks, split);
+  if (chunks_per_split) *chunks_per_split = cps;
+  return od_ceil_div(nchunks, cps);
+}
+
+// which kernel a layer takes: the 256-wide tile when it covers the [Cout][Ktot] matrix without much padding AND its one
+// round of workgroups fills most of the chip (measured per shape, profiles/r02/wgrad_bench.txt: the 1x1 layers and the
+// 10x10 maps with few tiles run 62-72 workgroups of it and are faster on the 128-wide kernel's 480+)
+static bool wgrad_use_w8(int cus, int M, int Cout, int Ktot) {
+  static int force = -2;
+  if (force == -2) {
+    const char* e = getenv("OD_WGRAD_W8");  // 0 = never, 1 = whenever possible (tuning)
+    force = e ? atoi(e) : -1;
+  }
+  if (force == 0) return false;
+  if (force == 1) return true;
+  const long long tiles = (long long)od_ceil_div(Cout, W8_TILE) * od_ceil_div(Ktot, W8_TILE);
+  const double eff = (double)Cout * Ktot / (double)(tiles * W8_TILE * W8_TILE);
+  const int split = wgrad_w8_split(cus, od_ceil_div(M, KC), Cout, Ktot, nullptr);
+  return eff >= 0.74 && tiles * split >= 160;
+}
+
 static int wgrad_split(const od_ctx* ctx, int M, int Cout, int Ktot, int* chunks_per_split) {
-  const int rtiles = od_ceil_div(Cout, TILE), ctiles = od_ceil_div(Ktot, TILE);
   const int nchunks = od_ceil_div(M, KC);
   const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
+  if (wgrad_use_w8(cus, M, Cout, Ktot)) return wgrad_w8_split(cus, nchunks, Cout, Ktot, chunks_per_split);
+  const int rtiles = od_ceil_div(Cout, TILE), ctiles = od_ceil_div(Ktot, TILE);
   static int split_mul = -1;  // workgroups per CU the pixel split aims at (OD_WGRAD_SPLIT; every workgroup emits a full
   if (split_mul < 0) {        // 64 KiB f32 tile, so more splits = more partial-sum traffic)
     const char* e = getenv("OD_WGRAD_SPLIT");
@@ -252,10 +444,18 @@ static int wgrad_impl(od_ctx* ctx, const void* x, const void* dz, float* dw, flo
   OD_REQUIRE(M64 * Cout < (1LL << 31) && (long long)B * H * W * Cin < (1LL << 31), "od_conv2d_bwd_weight: too large");
   p.M = (int)M64;
   p.HoWo = p.Ho * p.Wo;
-  p.rtiles = od_ceil_div(Cout, TILE);
-  p.ctiles = od_ceil_div(p.Ktot, TILE);
   p.split = wgrad_split(ctx, p.M, Cout, p.Ktot, &p.chunks_per_split);
   if (nsplit) *nsplit = p.split;
+  if (wgrad_use_w8(ctx->num_cu > 0 ? ctx->num_cu : 256, p.M, Cout, p.Ktot)) {
+    p.rtiles = od_ceil_div(Cout, W8_TILE);
+    p.ctiles = od_ceil_div(p.Ktot, W8_TILE);
+    if (int rc = od_ensure_lds(ctx, (const void*)&od_conv_wgrad_w8, (size_t)W8_LDS)) return rc;
+    hipLaunchKernelGGL(od_conv_wgrad_w8, dim3(p.rtiles * p.ctiles * p.split), dim3(512), W8_LDS, (hipStream_t)stream, p);
+    OD_CHECK_LAUNCH();
+    return OD_OK;
+  }
+  p.rtiles = od_ceil_div(Cout, TILE);
+  p.ctiles = od_ceil_div(p.Ktot, TILE);
   hipLaunchKernelGGL(od_conv_wgrad, dim3(p.rtiles * p.ctiles * p.split), dim3(256), 0, (hipStream_t)stream, p);
   OD_CHECK_LAUNCH();
   return OD_OK;

@@ -118,6 +118,14 @@ class Net:
                 self.ops[i].conv.splitk = 0
                 self.ops[i].conv.splitk_workspace = self.splitk_ws.data_ptr()
                 self.ops[i].conv.splitk_workspace_bytes = nbytes
+        # TIMING ABLATION ONLY (results become garbage): drop ops whose name matches a prefix*suffix pattern, to measure what a
+        # group of layers costs inside the running pipeline (scripts/dev/exp_ablate.sh); never set in tests / bench lines
+        abl = [q.partition("*") for q in filter(None, os.environ.get("OD_ABLATE_OPS", "").split(","))]
+        if abl:
+            keep = [i for i, inf in enumerate(self.op_info)
+                    if not any(inf["name"].startswith(pre) and inf["name"].endswith(suf) for pre, _s, suf in abl)]
+            self.ops = [self.ops[i] for i in keep]
+            self.op_info = [self.op_info[i] for i in keep]
         arr = (_lib.PlanOp * len(self.ops))(*self.ops)
         h = C.c_void_p()
         _lib.check(self.lib.od_plan_create(self.ctx.handle, arr, len(self.ops), C.byref(h)), "od_plan_create")

@@ -66,6 +66,10 @@ class Trainer:
         self.pb = PriorBoxes((self.H0, self.W0), self.num_classes, device=self.device)
         self.P = len(self.pb)
         dev = self.device
+        # od_conv_desc.tile_cfg of the forward / backward-data convolutions: -1 = fastest launch on an idle chip, -2 = least
+        # CU x time (the backward-data chain shares the chip with the weight-gradient stream)
+        self.fwd_tile_cfg = int(os.environ.get("OD_TRAIN_FWD_CFG", "-1"))
+        self.bwd_tile_cfg = int(os.environ.get("OD_TRAIN_BWD_CFG", "-1"))
 
         # ---- flat f32 parameter / gradient / momentum buffers -------------------------------------------------
         self.specs = {s[0]: s for s in W.layer_specs(self.num_classes, self.neck_ch, self.tower)}
@@ -268,7 +272,7 @@ class Trainer:
         d.scale, d.bias = self.ones.data_ptr(), (bias if bias is not None else self.zeros).data_ptr()
         d.out = out if isinstance(out, int) else out.data_ptr()
         d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride = self.B, n.H, n.W, n.Cin, n.Cout, n.k, n.stride
-        d.act, d.res_mode, d.tile_cfg = _lib.OD_ACT_LINEAR, _lib.OD_RES_NONE, -1
+        d.act, d.res_mode, d.tile_cfg = _lib.OD_ACT_LINEAR, _lib.OD_RES_NONE, self.fwd_tile_cfg
         d.out_dtype = _lib.OD_DT_F32 if out_f32 else _lib.OD_DT_F16
         d.out_batch_stride, d.out_pix_stride = obs, ops
         _lib.check(self.lib.od_conv2d_fwd(self.ctx.handle, C.byref(d), _stream_ptr()), f"conv fwd {n.name}")
@@ -393,12 +397,18 @@ class Trainer:
                 assert n.out in have, f"no gradient reached {n.out}"
                 dy = self.gradbuf[n.out]
                 if n.res:
-                    g = self._grad(n.res)
+                    if n.res_mode == "same" and n.res not in have:
+                        # first gradient to reach the shortcut's source: d(res) = dy.  No copy -- the source's gradient
+                        # tensor IS dy's buffer from here on (dy has no reader after this node's od_bn_bwd below, every
+                        # later contribution accumulates in place, all on this stream): a whole stage's residual stream
+                        # shares one gradient buffer, and 22 full-tensor copies per step (0.4 ms at 32 x 320^2) are gone
+                        self.gradbuf[n.res] = dy
+                        g = dy
+                    else:
+                        g = self._grad(n.res)
                     if n.res_mode == "same":
                         if n.res in have:
                             _lib.check(lib.od_add_f16(h, g.data_ptr(), dy.data_ptr(), dy.numel(), s), "od_add_f16")
-                        else:
-                            g.copy_(dy)
                     else:
                         _lib.check(lib.od_down2_sum_add(h, dy.data_ptr(), g.data_ptr(), self.B, Ho // 2, Wo // 2, n.Cout,
                                                         int(n.res in have), s), "od_down2_sum_add")
@@ -443,7 +453,7 @@ class Trainer:
             d.x, d.w, d.scale, d.bias = dz.data_ptr(), self.wb[n.name].data_ptr(), self.ones.data_ptr(), self.zeros.data_ptr()
             d.out = g.data_ptr()
             d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride = self.B, Ho, Wo, n.Cout, n.Cin, n.k, n.stride
-            d.act, d.out_dtype, d.tile_cfg = _lib.OD_ACT_LINEAR, _lib.OD_DT_F16, -1
+            d.act, d.out_dtype, d.tile_cfg = _lib.OD_ACT_LINEAR, _lib.OD_DT_F16, self.bwd_tile_cfg
             d.transposed = int(n.stride == 2)
             if n.x in have:
                 d.res, d.res_mode = g.data_ptr(), _lib.OD_RES_SAME  # accumulate in place

@@ -25,7 +25,8 @@ def main():
     shapes = [(320, 32, 64, 3, 2), (160, 64, 32, 1, 1), (160, 32, 64, 3, 1), (160, 64, 128, 3, 2), (80, 128, 64, 1, 1),
               (80, 64, 128, 3, 1), (80, 128, 256, 3, 2), (40, 256, 128, 1, 1), (40, 128, 256, 3, 1), (40, 256, 512, 3, 2),
               (20, 512, 256, 1, 1), (20, 256, 512, 3, 1), (20, 512, 1024, 3, 2), (10, 1024, 512, 1, 1), (10, 512, 1024, 3, 1),
-              (40, 256, 256, 3, 1)]
+              (40, 256, 256, 3, 1), (20, 256, 256, 3, 1), (10, 256, 256, 3, 1), (40, 256, 208, 3, 1), (40, 256, 256, 1, 1),
+              (20, 512, 256, 1, 1), (10, 1024, 256, 1, 1)]
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     tot = 0.0
     for H, Cin, Cout, k, stride in shapes:

@@ -60,59 +60,74 @@ def _f16_ulp(v):
     return np.spacing(np.abs(v).astype(np.float16)).astype(np.float32)
 
 
+def _abs_params(params, names):
+    """Parameters whose folded epilogue is |scale| * conv(|x|, |w|) + |bias|: the magnitude sum of every term of an output."""
+    q = {}
+    for n in names:
+        sc, bi = onet.fold_bn(params, n)
+        q[n + ".w"] = np.abs(params[n + ".w"])
+        q[n + ".gamma"], q[n + ".var"] = np.abs(sc), np.full_like(sc, 1.0 - onet.BN_EPS)  # -> scale = |sc| exactly enough
+        q[n + ".beta"], q[n + ".mean"] = np.abs(bi), np.zeros_like(bi)
+    return q
+
+
 def _check_layers_in_isolation(net, params, tag):
-    """Every op of the plan against the oracle ON THE DEVICE'S OWN INPUT of that op: given bit-identical inputs the only
-    differences left are f32 accumulation order and the last ulp of exp(), so the device's f16 output must equal the
-    oracle's rounded value except where the pre-rounding value sits on a rounding boundary -- never more than 1 f16 ulp
-    off (values below 2^-9 of the layer's rms are held to the ulp at that floor: there the f32 accumulation-order noise of
-    cancelling sums exceeds their own ulp), and only for a small fraction of the elements."""
+    """Every op of the plan against the oracle ON THE DEVICE'S OWN INPUT of that op.  Given bit-identical inputs the only
+    differences left are the f32 accumulation order and the last ulp of exp(), so the device's f16 output must equal the
+    oracle's rounded value except where the pre-rounding value sits on a rounding boundary:
+        |dev - f16(oracle)| <= 1 f16 ulp of the value + 2^-20 * (|scale| * sum |x||w| + |bias|)
+    -- the second term (16 f32 epsilons of the magnitude sum) is the accumulation-order noise of a cancelling sum, which can
+    exceed the own ulp of a near-zero output -- and only for a small fraction of the elements."""
     run = onet.Runner(params, storage="f32")
+    names = [s_[0] for s_ in onet.layer_specs(20)]
+    mag = onet.Runner(_abs_params(params, names), storage="f32", backbone_act=None, head_act=None)
     worst_frac, rows = 0.0, []
     for inf, kname in zip(net.op_info, net.time_ops()[1]):
         kind, name = inf["kind"], inf["name"]
         x = inf["x"].cpu().numpy()
         if kind == "first":
             r = run.first(x)
+            A = None
         elif kind == "stem":
             t = run.first(x).astype(np.float16).astype(np.float32)
             r = run.conv(t, "b.down1", stride=2, act=inf["act"])
+            A = mag.conv(np.abs(t), "b.down1", stride=2)
         elif kind == "bneck":
             xf = x.astype(np.float32)
             t = run.conv(xf, name + ".a", act=inf["act"]).astype(np.float16).astype(np.float32)
             r = run.conv(t, name + ".b", act=inf["act"], res=xf)
+            A = mag.conv(np.abs(t), name + ".b", res=np.abs(xf))
         else:
+            xf = x.astype(np.float32)
             res = None if inf["res"] is None else inf["res"].cpu().numpy().astype(np.float32)
-            r = run.conv(x.astype(np.float32), name, stride=inf["stride"], act=inf["act"], res=res,
+            r = run.conv(xf, name, stride=inf["stride"], act=inf["act"], res=res, res_up2=inf["res_mode"] == 2)
+            A = mag.conv(np.abs(xf), name, stride=inf["stride"], res=None if res is None else np.abs(res),
                          res_up2=inf["res_mode"] == 2)
         if kind == "conv" and inf["out_f32"]:
             off, rows_n = inf["pred_rows"]
             d = net.pred[:, off:off + rows_n].cpu().numpy().reshape(r.shape)
-            R = float(np.abs(r).max())
-            err = float(np.abs(d - r).max())
-            assert err <= 1e-5 * max(R, 1.0), (name, err, R)
-            rows.append((name, kname, "f32", err / max(R, 1.0), 0.0))
+            err = float((np.abs(d - r) / (2.0 ** -20 * A)).max())
+            assert err <= 1.0, (name, err)
+            rows.append((name, kname, "f32", err, 0.0))
             continue
         d = inf["out"].cpu().numpy().astype(np.float32)
         r16 = r.astype(np.float16).astype(np.float32)
         rms = float(np.sqrt(np.mean(r.astype(np.float64) ** 2)))
-        ulp = _f16_ulp(np.maximum(np.abs(r16), np.float32(rms / 512.0)))
+        tol = _f16_ulp(r16) + (np.float32(2.0 ** -20) * A if A is not None else np.float32(0))
+        if kind in ("stem", "bneck"):
+            # a fused op also rounds its hidden tensor to f16; where THAT rounding falls the other way (1e-4 of the hidden
+            # elements, measured on od_conv_first) nine-plus outputs move by w * ulp(t) -- up to a few 1e-3 of the layer's
+            # rms (scripts/dev/dbg_stem_iso.py: 787 of 13 M outputs, identical for the fused and the two-kernel path)
+            tol = tol + np.float32(4e-3 * rms)
         err = np.abs(d - r16)
         frac = float(np.mean(d != r16))
-        if kind in ("conv", "first"):
-            mx = float((err / ulp).max())
-            assert mx <= 1.0, f"{tag} {name} ({kname}): {mx:.2f} f16 ulps off the oracle on identical inputs"
-            assert frac <= 0.01, f"{tag} {name} ({kname}): {frac:.3%} of the outputs differ from the oracle on identical inputs"
-        else:
-            # a fused op (stem, residual block) also rounds its hidden tensor to f16; where THAT rounding falls the other way
-            # (1e-4 of the hidden elements, measured on od_conv_first) nine-plus outputs move by w * ulp(t) -- up to a few
-            # 1e-3 of the layer's rms, far more than the own ulp of a near-zero output (scripts/dev/dbg_stem_iso.py: 787 of
-            # 13 M outputs, identical for the fused and the two-kernel path).  So: one own ulp plus that absolute term.
-            mx = float((err / (ulp + np.float32(4e-3 * rms))).max())
-            assert mx <= 1.0, f"{tag} {name} ({kname}): {float(err.max()):.3e} off the oracle on identical inputs (rms {rms:.3f})"
-            assert frac <= 0.02, f"{tag} {name} ({kname}): {frac:.3%} of the outputs differ from the oracle on identical inputs"
+        mx = float((err / tol).max())
         rows.append((name, kname, "f16", mx, frac))
+        assert mx <= 1.0, f"{tag} {name} ({kname}): {float(err.max()):.3e} off the oracle on identical inputs (rms {rms:.3f}, {mx:.2f} x tol)"
+        assert frac <= 0.02, f"{tag} {name} ({kname}): {frac:.3%} of the outputs differ from the oracle on identical inputs"
         worst_frac = max(worst_frac, frac)
-    print(f"[{tag}] per-layer isolation: {len(rows)} ops, worst mismatch fraction {worst_frac:.2e}")
+    print(f"[{tag}] per-layer isolation: {len(rows)} ops, worst mismatch fraction {worst_frac:.2e}, "
+          f"worst error / tolerance {max(r_[3] for r_ in rows):.2f}")
     for r_ in sorted(rows, key=lambda t: -t[4])[:5]:
         print("    ", r_)
     return rows

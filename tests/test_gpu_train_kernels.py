@@ -74,6 +74,13 @@ CONV_CASES = [  # B, H, W, Cin, Cout, k, stride
     (2, 32, 32, 64, 128, 3, 2),    # stride 2: whole tiles per parity class (taps skipped per tile)
     (1, 12, 28, 32, 64, 3, 2),     # stride 2, 32 gradient channels out, non-square
     (2, 6, 10, 1024, 512, 1, 1),
+    # shapes that take the 8-wave 256 x 256 weight-gradient kernel (od_conv_wgrad_w8): whole tiles, ragged Ktot (6.75 tiles),
+    # ragged Cout (208), stride 2, one tap spread over two half-tiles (Cin = 256)
+    (2, 12, 12, 256, 256, 3, 1),
+    (2, 8, 8, 192, 256, 3, 1),
+    (3, 9, 9, 256, 208, 3, 1),
+    (2, 12, 20, 128, 256, 3, 2),
+    (2, 10, 10, 512, 256, 1, 1),
 ]
 
 
@@ -175,3 +182,45 @@ def test_bn_fold_bit_exact_vs_numpy(cuda):
         assert np.array_equal(sc.cpu().numpy(), rs) and np.array_equal(bi.cpu().numpy(), rb)
         rs2, rb2 = W.fold_bn(p, "l")
         assert np.array_equal(rs, rs2) and np.array_equal(rb, rb2)
+
+
+@pytest.mark.parametrize("case", [(8, 40, 40, 128, 256, 3, 1), (4, 20, 20, 256, 512, 3, 1), (32, 10, 10, 512, 1024, 3, 1),
+                                  (4, 40, 40, 256, 512, 3, 2), (16, 40, 40, 256, 128, 1, 1)], ids=str)
+def test_weight_gradient_slab_path_many_splits(cuda, case):
+    """The form the trainer uses: per-split f32 slabs (plain stores) + fixed-order reduce, at sizes where the pixel range is
+    split over many workgroups (33 splits of the 256-wide kernel on the first case).  vs torch conv2d weight gradient in
+    f64; two runs are bit-identical (no atomics anywhere)."""
+    import ctypes as C
+    from object_detector_amd import _lib
+    from object_detector_amd.net import Context
+    B, H, W, Cin, Cout, k, stride = case
+    rng = np.random.default_rng(7)
+    x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float16)
+    Ho, Wo = H // stride, W // stride
+    dz = rng.normal(0, 1, (B, Ho, Wo, Cout)).astype(np.float16)
+    xt = torch.tensor(x.astype(np.float64)).permute(0, 3, 1, 2)
+    wt = torch.zeros((Cout, Cin, k, k), dtype=torch.float64, requires_grad=True)
+    F.conv2d(xt, wt, stride=stride, padding=k // 2).backward(torch.tensor(dz.astype(np.float64)).permute(0, 3, 1, 2))
+    ref = wt.grad.permute(0, 2, 3, 1).numpy().reshape(Cout, k * k * Cin)
+    ctx = Context.get(cuda)
+    lib, h = ctx.lib, ctx.handle
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    xd, dzd = torch.from_numpy(x).to(cuda), torch.from_numpy(dz).to(cuda)
+    sp = lib.od_conv2d_bwd_weight_splits(h, B, H, W, Cin, Cout, k, stride)
+    assert sp >= 1
+    count = Cout * k * k * Cin
+    outs = []
+    for _ in range(2):
+        slabs = torch.full((sp * count,), float("nan"), dtype=torch.float32, device=cuda)  # every element must be written
+        _lib.check(lib.od_conv2d_bwd_weight_slabs(h, xd.data_ptr(), dzd.data_ptr(), slabs.data_ptr(), B, H, W, Cin, Cout, k,
+                                                  stride, s))
+        e = _lib.WgradRed()
+        e.dw_offset, e.count, e.slabs, e.nslabs = 0, count, slabs.data_ptr(), sp
+        tbl = torch.frombuffer(bytearray(bytes(e)), dtype=torch.uint8).to(cuda)
+        g = torch.empty(count, dtype=torch.float32, device=cuda)
+        _lib.check(lib.od_wgrad_reduce_multi(h, tbl.data_ptr(), 1, g.data_ptr(), s))
+        torch.cuda.synchronize()
+        outs.append(g.cpu().numpy().reshape(Cout, -1))
+    print(f"{case}: {sp} splits")
+    assert np.array_equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[0], ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
