@@ -315,9 +315,12 @@ int od_cast_f32_bf16(od_ctx* ctx, const float* src, void* dst, long long n, void
 int od_cast_bf16_f32(od_ctx* ctx, const void* src, float* dst, long long n, void* stream);
 int od_pack_weights_multi(od_ctx* ctx, const float* w, const od_pack_layer* layers, int nlayers, void* stream);
 
-/* first layer's weight gradient: dw f32 [32][27] += dz^T . shifted(x_u8) * in_scale (no dX: the input is the image) */
+/* first layer's weight gradient: dw f32 [32][27] += dz^T . shifted(x_u8) * in_scale (no dX: the input is the image).
+ * Runs the MFMA weight-gradient kernel over an f16 x 8-channel copy of the image kept in `workspace` (16 B per pixel + the
+ * per-split slabs); fixed-order slab sum, no atomics: bit-reproducible.  workspace: 16-byte aligned, caller-owned. */
+size_t od_conv_first_bwd_weight_workspace_bytes(od_ctx* ctx, int B, int H, int W);
 int od_conv_first_bwd_weight(od_ctx* ctx, const uint8_t* x, const void* dz, float* dw, int B, int H, int W, int Cout,
-                             float in_scale, void* stream);
+                             float in_scale, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K13: data-parallel gradient exchange over RCCL / xGMI (reference knob use_multi_gpu=True, check_assign.py:19).

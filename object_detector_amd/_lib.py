@@ -166,8 +166,9 @@ _PROTOS = {
     "od_pack_weights_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "od_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p]),
+    "od_conv_first_bwd_weight_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "od_conv_first_bwd_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                           C.c_int, C.c_float, C.c_void_p]),
+                                           C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     "od_comm_unique_id_bytes": (C.c_int, []),
     "od_comm_get_unique_id": (C.c_int, [C.c_void_p, C.c_int]),
     "od_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),

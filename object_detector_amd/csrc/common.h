@@ -64,3 +64,7 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
 const char* od_conv_first_kernel_name();
 const char* od_bottleneck_kernel_name(int C);
 const char* od_stem_kernel_name();
+
+// weight-gradient launcher (conv_wgrad.hip): per-split f32 slabs [split][Cout][k*k*Cin]; *nsplit receives the split count
+int od_wgrad_slabs_impl(od_ctx* ctx, const void* x, const void* dz, float* slabs, int B, int H, int W, int Cin, int Cout,
+                        int ksize, int stride, void* stream, int* nsplit);

@@ -108,71 +108,65 @@ extern "C" int od_conv_first_fwd(od_ctx* ctx, const uint8_t* x, const void* w, c
   return OD_OK;
 }
 
-// ---- K11 for the first layer: dW[co][tap*3 + c] += sum_pixels dz[pixel][co] * x_u8[shifted pixel][c] * in_scale -----
-// Tiny output (32 x 27), huge reduction: VALU kernel, one 8x32-pixel tile per workgroup, halo in LDS, per-workgroup
-// partial sums reduced through LDS, one f32 atomic per (co, k) per workgroup.  No dX (the input is the image).
+// ---- K11 for the first layer: dW[co][tap*3 + c] += in_scale * sum_pixels dz[pixel][co] * x_u8[shifted pixel][c] ----------
+// Tiny output (32 x 27), huge reduction (B*H*W pixels).  Round 1 ran it on the VALU (352 us at 32 x 320^2: one broadcast LDS
+// read + 3 FMAs per tap per pixel per lane).  Now: the image is widened once to f16 with 8 channels per pixel (r, g, b, 0 x 5:
+// 16 B, the granule of an LDS-DMA lane), and the GENERIC weight-gradient kernel (conv_wgrad.hip, MFMA, pixel index = k) runs on
+// it as a 3x3 conv with Cin = 8, Cout = 32 -> per-split slabs [split][32][72]; a last kernel sums the slabs in ascending order,
+// drops the 5 padding channels of every tap and applies in_scale.  No atomics: the result is bit-reproducible.  No dX (the
+// input is the image).
 namespace {
-constexpr int GTH = 8, GLH = GTH + 2;  // this kernel's own tile: 8 rows (one per 32-thread part) x 32 pixels
-__global__ __launch_bounds__(256) void od_conv_first_wgrad(const uint8_t* __restrict__ x, const f16* __restrict__ dz,
-                                                           float* __restrict__ dw, int H, int W, float in_scale) {
-  // halo tile converted to f32 ONCE ([row][pixel][4], 4th = 0): the inner loop is one 16-B LDS read + 3 FMAs per tap
-  // instead of a byte read + convert + FMA per (tap, channel)
-  __shared__ __attribute__((aligned(16))) float tile[GLH * LW * 4];
-  __shared__ float red[8][32][28];
-  const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * GTH, b = blockIdx.z;
-  for (int i = tid; i < GLH * LW; i += 256) {
-    const int r = i / LW, px = i - r * LW;
-    const int gy = y0 - 1 + r, gx = x0 - 1 + px;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-      const uint8_t* src = x + ((long long)(b * H + gy) * W + gx) * 3;
-      v[0] = (float)src[0];
-      v[1] = (float)src[1];
-      v[2] = (float)src[2];
-    }
-    *(f32x4*)(tile + i * 4) = v;
+__global__ __launch_bounds__(256) void od_u8_to_f16x8(const uint8_t* __restrict__ x, f16* __restrict__ out, long long npix) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+    const uint8_t* s = x + i * 3;
+    f16x8 v = {(f16)(float)s[0], (f16)(float)s[1], (f16)(float)s[2], (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+    *(f16x8*)(out + i * 8) = v;
   }
-  __syncthreads();
-  const int co = tid & 31, part = tid >> 5;  // part = tile row (8 rows of 32 pixels)
-  float acc[27];
+}
+// one wave per output element: lane l adds the slabs l, l+64, ... in ascending order, then a fixed butterfly over the
+// lanes -- the same summation tree on every run (bit-reproducible), 864 waves instead of one workgroup walking 512 slabs
+__global__ __launch_bounds__(256) void od_conv_first_wgrad_finish(const float* __restrict__ slabs, int nsplit,
+                                                                  float* __restrict__ dw, float in_scale) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // output element
+  const int lane = threadIdx.x & 63;
+  if (i >= 32 * 27) return;
+  const int co = i / 27, k = i - co * 27;
+  const int col = (k / 3) * 8 + (k % 3);
+  float s = 0.f;
+  for (int sp = lane; sp < nsplit; sp += 64) s += slabs[((long long)sp * 32 + co) * 72 + col];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
-  const int gy = y0 + part;
-  if (gy < H) {
-    const int nx = min(TW, W - x0);
-    const f16* dzp = dz + ((long long)(b * H + gy) * W + x0) * 32 + co;
-    for (int xx = 0; xx < nx; ++xx) {
-      const float d = (float)dzp[xx * 32];
-      const float* pb = tile + (part * LW + xx) * 4;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const f32x4 v = *(const f32x4*)(pb + ((tap / 3) * LW + tap % 3) * 4);
-        acc[tap * 3 + 0] += d * v[0];
-        acc[tap * 3 + 1] += d * v[1];
-        acc[tap * 3 + 2] += d * v[2];
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 27; ++k) red[part][co][k] = acc[k];
-  __syncthreads();
-  for (int i = tid; i < 32 * 27; i += 256) {
-    const int c2 = i / 27, k = i - c2 * 27;
-    float s = 0.f;
-#pragma unroll
-    for (int p2 = 0; p2 < 8; ++p2) s += red[p2][c2][k];
-    atomicAdd(dw + c2 * 27 + k, s * in_scale);
-  }
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) dw[i] += s * in_scale;
 }
 }  // namespace
 
+extern "C" size_t od_conv_first_bwd_weight_workspace_bytes(od_ctx* ctx, int B, int H, int W) {
+  if (!ctx || B <= 0 || H <= 0 || W <= 0) return 0;
+  const size_t x8 = (size_t)B * H * W * 16;
+  const int split = od_conv2d_bwd_weight_splits(ctx, B, H, W, 8, 32, 3, 1);
+  return x8 + (size_t)split * 32 * 72 * sizeof(float);
+}
+
 extern "C" int od_conv_first_bwd_weight(od_ctx* ctx, const uint8_t* x, const void* dz, float* dw, int B, int H, int W,
-                                        int Cout, float in_scale, void* stream) {
-  OD_REQUIRE(ctx && x && dz && dw && Cout == 32 && B > 0 && H > 0 && W > 0 && B <= 65535,
+                                        int Cout, float in_scale, void* workspace, size_t workspace_bytes, void* stream) {
+  OD_REQUIRE(ctx && x && dz && dw && workspace && Cout == 32 && B > 0 && H > 0 && W > 0,
              "od_conv_first_bwd_weight: bad argument (Cout must be 32)");
-  dim3 grid(od_ceil_div(W, TW), od_ceil_div(H, GTH), B);
-  hipLaunchKernelGGL(od_conv_first_wgrad, grid, dim3(256), 0, (hipStream_t)stream, x, (const f16*)dz, dw, H, W, in_scale);
+  if (workspace_bytes < od_conv_first_bwd_weight_workspace_bytes(ctx, B, H, W)) {
+    od_set_error("od_conv_first_bwd_weight: workspace too small");
+    return OD_ERR_WORKSPACE;
+  }
+  OD_REQUIRE(((uintptr_t)workspace & 15) == 0, "od_conv_first_bwd_weight: workspace must be 16-byte aligned");
+  const long long npix = (long long)B * H * W;
+  f16* x8 = (f16*)workspace;
+  float* slabs = (float*)((char*)workspace + (size_t)npix * 16);
+  long long blocks = (npix + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(od_u8_to_f16x8, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x8, npix);
+  OD_CHECK_LAUNCH();
+  int nsplit = 0;
+  if (int rc = od_wgrad_slabs_impl(ctx, x8, dz, slabs, B, H, W, 8, 32, 3, 1, stream, &nsplit)) return rc;
+  hipLaunchKernelGGL(od_conv_first_wgrad_finish, dim3(32 * 27 / 4), dim3(256), 0, (hipStream_t)stream, slabs, nsplit, dw,
+                     in_scale);
   OD_CHECK_LAUNCH();
   return OD_OK;
 }

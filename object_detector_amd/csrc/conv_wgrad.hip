@@ -374,6 +374,12 @@ __global__ __launch_bounds__(512, 2) void od_conv_wgrad_w8(WgradKP p) {
 // chunks per workgroup so that the pipeline fill and the 256-KiB partial-tile store stay a small part of it
 static int wgrad_w8_split(int cus, int nchunks, int Cout, int Ktot, int* chunks_per_split) {
   const int tiles = od_ceil_div(Cout, W8_TILE) * od_ceil_div(Ktot, W8_TILE);
+  static int target = -1;  // workgroups one launch aims at (OD_WGRAD_W8_WGS; default = every CU)
+  if (target < 0) {
+    const char* e = getenv("OD_WGRAD_W8_WGS");
+    target = e ? atoi(e) : 0;
+  }
+  if (target > 0) cus = target;
   int split = cus / tiles;
   if (split < 1) split = 1;
   if (split > nchunks / 12) split = nchunks / 12 > 0 ? nchunks / 12 : 1;
@@ -396,7 +402,12 @@ static bool wgrad_use_w8(int cus, int M, int Cout, int Ktot) {
   const long long tiles = (long long)od_ceil_div(Cout, W8_TILE) * od_ceil_div(Ktot, W8_TILE);
   const double eff = (double)Cout * Ktot / (double)(tiles * W8_TILE * W8_TILE);
   const int split = wgrad_w8_split(cus, od_ceil_div(M, KC), Cout, Ktot, nullptr);
-  return eff >= 0.74 && tiles * split >= 160;
+  static int min_wgs = -1;
+  if (min_wgs < 0) {
+    const char* e = getenv("OD_WGRAD_W8_MIN");
+    min_wgs = e ? atoi(e) : 160;
+  }
+  return eff >= 0.74 && tiles * split >= min_wgs;
 }
 
 static int wgrad_split(const od_ctx* ctx, int M, int Cout, int Ktot, int* chunks_per_split) {
@@ -459,6 +470,12 @@ static int wgrad_impl(od_ctx* ctx, const void* x, const void* dz, float* dw, flo
   hipLaunchKernelGGL(od_conv_wgrad, dim3(p.rtiles * p.ctiles * p.split), dim3(256), 0, (hipStream_t)stream, p);
   OD_CHECK_LAUNCH();
   return OD_OK;
+}
+
+// for conv_first.hip (the first layer's weight gradient runs on this kernel over an f16 x 8-channel copy of the image)
+int od_wgrad_slabs_impl(od_ctx* ctx, const void* x, const void* dz, float* slabs, int B, int H, int W, int Cin, int Cout,
+                        int ksize, int stride, void* stream, int* nsplit) {
+  return wgrad_impl(ctx, x, dz, nullptr, slabs, B, H, W, Cin, Cout, ksize, stride, stream, nsplit);
 }
 
 extern "C" int od_conv2d_bwd_weight(od_ctx* ctx, const void* x, const void* dz, float* dw, int B, int H, int W, int Cin,

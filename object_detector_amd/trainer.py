@@ -429,8 +429,12 @@ class Trainer:
                 self.wstream.wait_event(ev)
                 ws = C.c_void_p(self.wstream.cuda_stream)
             if n.first:
+                if getattr(self, "_first_ws", None) is None:
+                    nb = lib.od_conv_first_bwd_weight_workspace_bytes(h, self.B, n.H, n.W)
+                    self._first_ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
                 _lib.check(lib.od_conv_first_bwd_weight(h, x.data_ptr(), dz.data_ptr(), dw.data_ptr(), self.B, n.H, n.W,
-                                                        n.Cout, 1.0 / 255.0, ws), "od_conv_first_bwd_weight")
+                                                        n.Cout, 1.0 / 255.0, self._first_ws.data_ptr(),
+                                                        self._first_ws.numel(), ws), "od_conv_first_bwd_weight")
             else:
                 _lib.check(lib.od_conv2d_bwd_weight_slabs(h, x.data_ptr(), dz.data_ptr(), self._slab_ptr[id(n)], self.B, n.H,
                                                           n.W, n.Cin, n.Cout, n.k, n.stride, ws), f"wgrad {n.name}")

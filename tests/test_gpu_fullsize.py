@@ -302,3 +302,73 @@ def test_load_voc_round_trip_validate_defaults(cuda, tmp_path):
         r, *_ = onms.detect_image(conf[b], boxes[b], K=1024, conf_threshold=0.01, iou_threshold=0.45, max_det=200)
         assert cnt[b] == len(r) and (keep[b, :len(r)] == r).all()
         assert np.array_equal(preds[b].flat_indices, r)
+
+
+def test_voc_validate_on_a_voc07_layout_directory(cuda, tmp_path):
+    """BASELINE.json configs[0]: `voc_validate.py` on 10 VOC07 images at 320x320 -- the reference's acceptance entry point
+    (voc_validate.py:9-31) with its own defaults, reading a VOCdevkit-layout directory (JPEGImages / Annotations /
+    ImageSets/Main/test.txt; synthetic images of mixed sizes, since the dataset is not available offline) and a weights file
+    through `load_voc`.  The logged mAP must equal what the HOST pipeline computes for the same images with the CPU oracle's NMS
+    fed the device's conf / boxes: JPEG decode + resize, network, decode, NMS, box mapping and the VOC evaluator are all on
+    the path."""
+    import subprocess
+    import sys
+    from PIL import Image
+    from object_detector_amd import weights as W
+    from object_detector_amd.detector import ObjectDetector, ObjectsPrediction, load_image
+    from object_detector_amd.priors import DEFAULT_PRIOR_WH
+    import pytoolkit as tk
+    rng = np.random.default_rng(42)
+    base = tmp_path / "VOCdevkit" / "VOC2007"
+    for d in ("Annotations", "JPEGImages", "ImageSets/Main"):
+        (base / d).mkdir(parents=True, exist_ok=True)
+    ids = []
+    for i in range(10):
+        h, w = int(rng.integers(200, 500)), int(rng.integers(200, 500))
+        low = rng.integers(0, 256, (h // 8 + 1, w // 8 + 1, 3), dtype=np.uint8)  # blocky, so JPEG keeps some structure
+        img = np.repeat(np.repeat(low, 8, 0), 8, 1)[:h, :w]
+        name = f"{i:06d}"
+        ids.append(name)
+        Image.fromarray(img).save(base / "JPEGImages" / f"{name}.jpg", quality=90)
+        objs = ""
+        for _ in range(int(rng.integers(1, 4))):
+            x1, y1 = int(rng.integers(1, w // 2)), int(rng.integers(1, h // 2))
+            x2, y2 = int(rng.integers(x1 + 20, w)), int(rng.integers(y1 + 20, h))
+            cls = tk.data.voc.CLASS_NAMES[int(rng.integers(0, 20))]
+            objs += (f"<object><name>{cls}</name><difficult>0</difficult><bndbox><xmin>{x1}</xmin><ymin>{y1}</ymin>"
+                     f"<xmax>{x2}</xmax><ymax>{y2}</ymax></bndbox></object>\n")
+        (base / "Annotations" / f"{name}.xml").write_text(
+            f"<annotation><filename>{name}.jpg</filename><size><width>{w}</width><height>{h}</height><depth>3</depth></size>\n"
+            f"{objs}</annotation>")
+    (base / "ImageSets" / "Main" / "test.txt").write_text("\n".join(ids))
+    params = W.random_init(2)
+    wpath = tmp_path / "voc.npz"
+    W.save(wpath, params, meta={"prior_wh": np.asarray(DEFAULT_PRIOR_WH)})
+    res = tmp_path / "results"
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "voc_validate.py"), "--vocdevkit-dir", str(tmp_path / "VOCdevkit"),
+                        "--result-dir", str(res), "--weights", str(wpath)], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in (res / "validate.log").read_text().splitlines() if "mAP=" in ln]
+    assert len(line) == 1
+    # the same through the API, with the oracle's NMS on the device's conf / boxes
+    X, y = tk.data.voc.load_07_test(tmp_path / "VOCdevkit")
+    assert len(X) == 10
+    od = ObjectDetector.load_voc(16, input_size=(320, 320), keep_aspect=False, strict_nms=False, use_multi_gpu=False,
+                                 weights=str(wpath))
+    batch = np.zeros((16, 320, 320, 3), np.uint8)
+    for i, pth in enumerate(X):
+        batch[i] = load_image(pth, (320, 320), False)
+    keep, cnt = od.predict_batch_device(torch.from_numpy(batch).to(cuda), conf_threshold=0.01)
+    torch.cuda.synchronize()
+    conf, boxes = od.post.conf.cpu().numpy(), od.post.boxes.cpu().numpy()
+    preds = []
+    for b in range(10):
+        k, *_ = onms.detect_image(conf[b], boxes[b], K=1024, conf_threshold=0.01, iou_threshold=0.45, max_det=200)
+        assert cnt[b].item() == len(k) and (keep[b, :len(k)].cpu().numpy() == k).all()
+        preds.append(ObjectsPrediction(k % 20, conf[b].reshape(-1)[k], boxes[b][k // 20], k))
+    s = tk.data.voc.evaluate(y, preds)
+    want = f'mAP={s["mAP"] * 100:.1f} mAP(VOC2007)={s["mAP_VOC"] * 100:.1f}'
+    assert want in line[0], (want, line[0])
+    api = od.predict(list(X))
+    for a, b in zip(api, preds):
+        assert np.array_equal(a.flat_indices, b.flat_indices) and np.array_equal(a.bboxes, b.bboxes)
