@@ -66,6 +66,48 @@ def test_ctypes_structs_match_library_layout():
     assert lib.od_sizeof(b"no_such_struct") == -1 and lib.od_offsetof(b"od_conv_desc", b"nope") == -1
 
 
+def test_ctypes_prototypes_match_header():
+    """Every prototype of _lib._PROTOS against the declaration in include/odhip.h: same number of parameters, and each
+    parameter of the same KIND (pointer / int / long long / float / size_t) -- a binding that drifts from the header would
+    otherwise pass garbage without any error (ctypes cannot check it)."""
+    import ctypes as C
+    from object_detector_amd import _lib
+    hdr = (ROOT / "include" / "odhip.h").read_text()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    hdr = re.sub(r"typedef struct \w+ \{.*?\} \w+;", "", hdr, flags=re.S)
+    decls = re.findall(r"\n\s*([A-Za-z_][\w \*]*?)\b(od_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr)
+    assert len(decls) >= 60
+
+    def kind_of_c(tp):
+        tp = tp.strip()
+        if tp == "void" or tp == "":
+            return None
+        if "*" in tp:
+            return "ptr"
+        base = re.sub(r"\b[A-Za-z_]\w*$", "", tp).strip() or tp  # drop the parameter name
+        base = base.replace("const", "").strip()
+        return {"int": "i32", "int32_t": "i32", "float": "f32", "long long": "i64", "size_t": "i64", "long": "i64"}[base]
+
+    def kind_of_ctypes(ct):
+        if ct in (C.c_void_p, C.c_char_p) or hasattr(ct, "contents") or hasattr(ct, "_type_") and isinstance(ct._type_, type):
+            return "ptr"
+        assert ct in (C.c_int, C.c_int32, C.c_float, C.c_longlong, C.c_size_t, C.c_long), ct
+        return "f32" if ct is C.c_float else ("i32" if C.sizeof(ct) == 4 else "i64")  # LP64: long / long long / size_t = 8 B
+
+    seen = set()
+    for ret, name, params in decls:
+        assert name in _lib._PROTOS, name
+        res, args = _lib._PROTOS[name]
+        cparams = [k for k in (kind_of_c(q) for q in params.split(",")) if k is not None]
+        got = [kind_of_ctypes(a) for a in args]
+        assert got == cparams, (name, cparams, got)
+        rk = ret.replace("const", "").strip()
+        want_res = {"int": 4, "size_t": 8, "long": 8, "char*": 8, "char *": 8}[rk]
+        assert C.sizeof(res) == want_res and (res is C.c_char_p) == ("char" in rk), (name, rk, res)
+        seen.add(name)
+    assert seen == set(_lib._PROTOS), set(_lib._PROTOS) ^ seen
+
+
 def test_integration_md_declarations_match_library():
     """INTEGRATION.md §2, first code block executed VERBATIM (only the library path is made absolute): the documented
     ConvDesc must be the library's od_conv_desc (round 1 shipped a stub four fields short)."""
