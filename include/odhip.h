@@ -99,11 +99,19 @@ typedef struct od_conv_desc {
   int32_t splitk;     /* split-K factor for small-M layers: 0 = library decides, 1 = off; needs splitk_workspace */
   void* splitk_workspace; /* f32 scratch for the partial slabs [splitk][B*Ho*Wo*Cout] (NULL = never split) */
   int64_t splitk_workspace_bytes; /* its size; the factor is clamped so that the slabs fit */
+  float* bn_partials; /* training forward (NULL otherwise): the epilogue also writes per-channel partial sums of the f16
+                         values it stores, one row per m-tile: f32 [rows][2][Cout] = (sum z, sum z^2), rows =
+                         od_conv2d_fwd_bn_rows(); od_bn_stats_from_partials turns them into the batch statistics, so the
+                         separate pass of od_bn_stats over z is not needed.  Needs out_dtype f16; disables split-K */
+  int64_t bn_partials_bytes;
 } od_conv_desc;
 
 int od_conv_weight_dims(int cout, int cin, int ksize, int* cout_pad, int* kpad);
 int od_conv_num_tile_cfgs(void);
 int od_conv2d_fwd(od_ctx* ctx, const od_conv_desc* d, void* stream);
+/* number of partial rows a launch of this descriptor writes into bn_partials (depends on the tile the library picks);
+ * <= 0 on error */
+int od_conv2d_fwd_bn_rows(od_ctx* ctx, const od_conv_desc* d);
 
 /* K1+K2 fused residual block of the early Darknet53 stages (one launch instead of two layers + add):
  *   out = x + act(scale3 * conv3x3(act(scale1 * conv1x1(x) + bias1)) + bias3)
@@ -249,6 +257,11 @@ size_t od_bn_workspace_bytes(long long M, int C);
 int od_bn_stats(od_ctx* ctx, const void* z, long long M, int C, const float* gamma, const float* beta, float eps,
                 float* mean, float* rstd, float* scale, float* shift, float* run_mean, float* run_var, float momentum,
                 void* workspace, size_t workspace_bytes, void* stream);
+/* the same statistics from the partial rows a conv epilogue wrote (od_conv_desc.bn_partials): fixed-order sum over the
+ * rows, then mean / rstd / scale / shift / running statistics exactly as od_bn_stats computes them */
+int od_bn_stats_from_partials(od_ctx* ctx, const float* partials, int rows, long long M, int C, const float* gamma,
+                              const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
+                              float* run_mean, float* run_var, float momentum, void* stream);
 /* y = act(scale*z + shift) (+ res / up2(res)), f16 */
 int od_scale_act(od_ctx* ctx, const void* z, const float* scale, const float* shift, const void* res, int res_mode,
                  void* y, int B, int H, int W, int C, int act, float alpha, void* stream);

@@ -31,6 +31,7 @@ class ConvDesc(C.Structure):
         ("out_batch_stride", C.c_int64), ("out_pix_stride", C.c_int64),
         ("tile_cfg", C.c_int32), ("transposed", C.c_int32), ("splitk", C.c_int32),
         ("splitk_workspace", C.c_void_p), ("splitk_workspace_bytes", C.c_int64),
+        ("bn_partials", C.c_void_p), ("bn_partials_bytes", C.c_int64),
     ]
 
 
@@ -104,6 +105,7 @@ _PROTOS = {
     "od_conv_weight_dims": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "od_conv_num_tile_cfgs": (C.c_int, []),
     "od_conv2d_fwd": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_void_p]),
+    "od_conv2d_fwd_bn_rows": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),
     "od_stem_supported": (C.c_int, [C.c_int, C.c_int]),
     "od_stem_fwd": (C.c_int, [C.c_void_p, C.POINTER(StemDesc), C.c_void_p]),
     "od_bottleneck_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
@@ -140,6 +142,9 @@ _PROTOS = {
     "od_bn_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                               C.c_void_p, C.c_size_t, C.c_void_p]),
+    "od_bn_stats_from_partials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_float, C.c_void_p]),
     "od_scale_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "od_bn_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -24,6 +24,9 @@ struct ConvKP {
   int tconv, Hs, Ws;  // transposed (backward-data of a stride-2 conv): x is [B,Hs,Ws,Cin], gathered through a 2x zero-upsampled view
   unsigned x_bytes, w_bytes;  // extents of x / packed w (buffer-addressed loaders: out-of-range lanes read zeros)
   int dbg;  // tuning ablations (OD_CONV_DEBUG): bit0 = skip the DMA, bit1 = skip fragment reads + MFMA
+  // training forward (od_conv_desc.bn_partials): per-channel partial sums of the STORED f16 outputs of this tile, row
+  // mtile of [mtiles][2][Cout] f32 = (sum z, sum z^2): the BatchNorm statistics pass over z disappears
+  float* stats;
 };
 
 static __device__ __forceinline__ void glds16(const void* gptr, void* lptr) {
@@ -80,7 +83,7 @@ static __device__ __forceinline__ int od_tconv_pixel(const ConvKP& p, unsigned m
 // ---- epilogue shared by every conv kernel: accumulators -> LDS staging (one wave-row of the tile at a time) ->
 //      scale/bias/act (+ residual) in f32 on full NHWC lines, ONE rounding to f16, 16-B stores.
 //      acc[i][j][e] holds pixel (wave-row base + i*16 + l15), channel (wn*WTN + j*16 + lq*4 + e).
-template <int BN, int WM, int WN, int MT, int NTL, int NT = WM * WN * 64>
+template <int BN, int WM, int WN, int MT, int NTL, int NT = WM * WN * 64, bool STATS = false>
 static __device__ __forceinline__ void conv_epilogue(const ConvKP& p, char* smem, f32x4 (&acc)[MT][NTL], int m0, int n0,
                                                      int tid, int wm, int wn, int l15, int lq) {
   constexpr int WTM = MT * 16, WTN = NTL * 16, SLD = BN + 4;
@@ -90,7 +93,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvKP& p, char* smem
   const int c8 = (tid % CH) * 8;
   const int n = n0 + c8;
   float sc[8], bi[8];
-  {
+  if (!STATS) {
     const f32x4 s0 = *(const f32x4*)(p.scale + n), s1 = *(const f32x4*)(p.scale + n + 4);
     const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
 #pragma unroll
@@ -100,6 +103,13 @@ static __device__ __forceinline__ void conv_epilogue(const ConvKP& p, char* smem
       bi[e] = b0[e];
       bi[4 + e] = b1[e];
     }
+  }
+  // STATS instantiations (training forward, od_conv_desc.bn_partials): the launcher guarantees the identity epilogue
+  // (scale = 1, bias = 0, no activation, no residual, no split-K), so the 16 scale / bias registers are free for the sums
+  float st0[STATS ? 8 : 1], st1[STATS ? 8 : 1];
+  if (STATS) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st0[e] = st1[e] = 0.f;
   }
   // residual rows are fetched up front (one 16-B load per store pass, all in flight together) so that their HBM/L2
   // latency overlaps the LDS staging instead of serialising pass after pass
@@ -166,16 +176,19 @@ static __device__ __forceinline__ void conv_epilogue(const ConvKP& p, char* smem
         const f32x4 v0 = *(const f32x4*)(stg + row * SLD + c8);
         const f32x4 v1 = *(const f32x4*)(stg + row * SLD + c8 + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (!STATS) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
-        if (p.act == OD_ACT_LEAKY) {
+          for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
+        }
+        if (STATS) {
+        } else if (p.act == OD_ACT_LEAKY) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = od_leaky(v[e], p.alpha);
         } else if (p.act == OD_ACT_ELU) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : p.alpha * od_expm1_fast(v[e]);
         }
-        if (p.res_mode != OD_RES_NONE) {
+        if (!STATS && p.res_mode != OD_RES_NONE) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += (float)resv[wr][ps][e];
         }
@@ -191,10 +204,60 @@ static __device__ __forceinline__ void conv_epilogue(const ConvKP& p, char* smem
 #pragma unroll
           for (int e = 0; e < 8; ++e) h[e] = (f16)v[e];
           *(f16x8*)((f16*)p.out + ooff) = h;
+          if (STATS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float q = (float)h[e];  // the stored value: what a separate statistics pass over z would read
+              st0[e] += q;
+              st1[e] += q * q;
+            }
+          }
         }
       }
     }
     if (wr + 1 < WM) __syncthreads();
+  }
+  if (STATS) {
+    // fixed-order reduction over the threads that own the same 8-channel chunk (tid % CH): butterfly over the lanes of a
+    // wave (CH divides 64), then over the waves through LDS; one partial row per m-tile -> bit-reproducible statistics
+    static_assert(CH == 8 || CH == 16 || CH == 32, "BN must be 64, 128 or 256");
+#pragma unroll
+    for (int off = CH; off < 64; off <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        st0[e] += __shfl_xor(st0[e], off, 64);
+        st1[e] += __shfl_xor(st1[e], off, 64);
+      }
+    }
+    __syncthreads();  // the staging rows of the last pass have been read
+    float* red = (float*)smem;  // [NT / 64][CH][16]
+    const int wv = tid >> 6, ln = tid & 63;
+    if (ln < CH) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wv * CH + ln) * 16 + e] = st0[e];
+        red[(wv * CH + ln) * 16 + 8 + e] = st1[e];
+      }
+    }
+    __syncthreads();
+    if (tid < CH && n < p.Cout) {
+      float a[8], b[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = b[e] = 0.f;
+      for (int w2 = 0; w2 < NT / 64; ++w2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          a[e] += red[(w2 * CH + tid) * 16 + e];
+          b[e] += red[(w2 * CH + tid) * 16 + 8 + e];
+        }
+      }
+      float* row = p.stats + (long long)(m0 / (WM * WTM)) * 2 * p.Cout;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        row[n + e] = a[e];
+        row[p.Cout + n + e] = b[e];
+      }
+    }
   }
 }
 

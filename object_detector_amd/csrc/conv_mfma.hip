@@ -50,7 +50,7 @@ struct ConvCfg {
 // SPEC: wave specialisation.  The workgroup has 2 x WM*WN waves: the first half only runs MFMAs (consumers), the second
 // half only issues the LDS-DMA (loaders) -- an LDS-DMA instruction costs its issuing wave ~70 cycles, which otherwise
 // comes straight out of the MFMA stream.  Both halves meet at the same per-step barrier.
-template <int BM, int BN, int BK, int STAGES, int WM, int WN, int KS, int MINW, bool UNI, int SPEC>
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, int KS, int MINW, bool UNI, int SPEC, bool STATS = false>
 __global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), MINW) void od_conv_igemm(ConvKP p) {
   using Cf = ConvCfg<BM, BN, BK, STAGES, WM, WN, SPEC>;
   constexpr int NT = Cf::NT, AR = Cf::AR, BR = Cf::BR, RPR = Cf::RPR, ROWB = Cf::ROWB;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), MINW) void od_conv_ig
   }
   __syncthreads();  // all fragment reads done before the ring is reused as epilogue staging
 
-  conv_epilogue<BN, WM, WN, MT, NTL, Cf::NTHREADS>(p, smem, acc, m0, n0, tid_all, is_consumer ? wm : -1, wn, l15, lq);
+  conv_epilogue<BN, WM, WN, MT, NTL, Cf::NTHREADS, STATS>(p, smem, acc, m0, n0, tid_all, is_consumer ? wm : -1, wn, l15, lq);
 }
 
 // split-K finish: out = act(scale * sum_s slab[s] + bias) (+ residual); slabs summed in ascending s (deterministic)
@@ -377,7 +377,7 @@ struct TileCfg {
 #define OD_STR2(x) #x
 #define OD_STR(x) OD_STR2(x)
 #define OD_NAME(BM, BN, BK, ST, WM, WN, KS, MINW, UNI)                                                              \
-  "od_conv_igemm<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", " OD_STR(WM) ", " OD_STR(WN) ", " OD_STR(KS) ", " OD_STR(MINW) ", " #UNI ", 0>"
+  "od_conv_igemm<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", " OD_STR(WM) ", " OD_STR(WN) ", " OD_STR(KS) ", " OD_STR(MINW) ", " #UNI ", 0, false>"
 #define OD_CFG(BM, BN, BK, ST, WM, WN, MINW)                                                                        \
   {                                                                                                                 \
     BM, BN, BK, WM* WN * 64, (size_t)ConvCfg<BM, BN, BK, ST, WM, WN>::LDS_BYTES,                                    \
@@ -390,16 +390,16 @@ struct TileCfg {
     BM, BN, BK, WM* WN * 128, (size_t)ConvCfg<BM, BN, BK, ST, WM, WN, 1>::LDS_BYTES,                                \
         (const void*)&od_conv_igemm<BM, BN, BK, ST, WM, WN, 1, MINW, true, 1>,                                      \
         (const void*)&od_conv_igemm<BM, BN, BK, ST, WM, WN, 3, MINW, true, 1>, nullptr,                             \
-        "od_conv_igemm<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", " OD_STR(WM) ", " OD_STR(WN) ", 1, " OD_STR(MINW) ", true, 1>", \
-        "od_conv_igemm<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", " OD_STR(WM) ", " OD_STR(WN) ", 3, " OD_STR(MINW) ", true, 1>", "" \
+        "od_conv_igemm<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", " OD_STR(WM) ", " OD_STR(WN) ", 1, " OD_STR(MINW) ", true, 1, false>", \
+        "od_conv_igemm<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", " OD_STR(WM) ", " OD_STR(WN) ", 3, " OD_STR(MINW) ", true, 1, false>", "" \
   }
 #define OD_CFG_S2(BM, BN, BK, ST, WM, WN, MINW)                                                                     \
   {                                                                                                                 \
     BM, BN, BK, WM* WN * 128, (size_t)ConvCfg<BM, BN, BK, ST, WM, WN, 1>::LDS_BYTES,                                \
         (const void*)&od_conv_igemm<BM, BN, BK, ST, WM, WN, 1, MINW, true, 2>,                                      \
         (const void*)&od_conv_igemm<BM, BN, BK, ST, WM, WN, 3, MINW, true, 2>, nullptr,                             \
-        "od_conv_igemm<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", " OD_STR(WM) ", " OD_STR(WN) ", 1, " OD_STR(MINW) ", true, 2>", \
-        "od_conv_igemm<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", " OD_STR(WM) ", " OD_STR(WN) ", 3, " OD_STR(MINW) ", true, 2>", "" \
+        "od_conv_igemm<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", " OD_STR(WM) ", " OD_STR(WN) ", 1, " OD_STR(MINW) ", true, 2, false>", \
+        "od_conv_igemm<" OD_STR(BM) ", " OD_STR(BN) ", " OD_STR(BK) ", " OD_STR(ST) ", " OD_STR(WM) ", " OD_STR(WN) ", 3, " OD_STR(MINW) ", true, 2, false>", "" \
   }
 #define OD_CFG_G(BM, BN, BK, ST, WM, WN, MINW)                                                                      \
   {                                                                                                                 \
@@ -445,6 +445,24 @@ const TileCfg g_cfgs[] = {
     OD_CFG(128, 128, 64, 4, 2, 2, 1),    // 29: 128 KiB
 };
 constexpr int kNumCfgs = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
+
+// STATS instantiations (od_conv_desc.bn_partials: BatchNorm partial sums written by the epilogue) of the table configs the
+// training forward pass is given: variant 0 = 1x1, 1 = 3x3 tap-uniform, 2 = 3x3 generic.  nullptr = not instantiated.
+#define OD_ST(BM, BN, BK, ST, WM, WN, KS, MINW, UNI, SPEC) (const void*)&od_conv_igemm<BM, BN, BK, ST, WM, WN, KS, MINW, UNI, SPEC, true>
+const void* stats_kernel(int cfg, int variant) {
+  switch (cfg) {
+    case 0: return variant == 0 ? OD_ST(128, 128, 64, 2, 2, 2, 1, 2, true, 0) : variant == 1 ? OD_ST(128, 128, 64, 2, 2, 2, 3, 2, true, 0) : OD_ST(128, 128, 64, 2, 2, 2, 3, 2, false, 0);
+    case 1: return variant == 0 ? OD_ST(128, 64, 64, 2, 2, 2, 1, 2, true, 0) : variant == 1 ? OD_ST(128, 64, 64, 2, 2, 2, 3, 2, true, 0) : OD_ST(128, 64, 64, 2, 2, 2, 3, 2, false, 0);
+    case 2: return variant == 0 ? OD_ST(64, 128, 64, 2, 2, 2, 1, 2, true, 0) : variant == 1 ? OD_ST(64, 128, 64, 2, 2, 2, 3, 2, true, 0) : OD_ST(64, 128, 64, 2, 2, 2, 3, 2, false, 0);
+    case 3: return variant == 0 ? OD_ST(64, 64, 64, 2, 2, 2, 1, 2, true, 0) : variant == 1 ? OD_ST(64, 64, 64, 2, 2, 2, 3, 2, true, 0) : OD_ST(64, 64, 64, 2, 2, 2, 3, 2, false, 0);
+    case 13: return variant == 0 ? OD_ST(128, 128, 64, 2, 2, 2, 1, 4, true, 1) : variant == 1 ? OD_ST(128, 128, 64, 2, 2, 2, 3, 4, true, 1) : nullptr;
+    case 14: return variant == 0 ? OD_ST(128, 128, 64, 3, 2, 2, 1, 2, true, 1) : variant == 1 ? OD_ST(128, 128, 64, 3, 2, 2, 3, 2, true, 1) : nullptr;
+    case 24: return variant == 0 ? OD_ST(64, 64, 64, 4, 2, 2, 1, 2, true, 0) : variant == 1 ? OD_ST(64, 64, 64, 4, 2, 2, 3, 2, true, 0) : nullptr;
+    case 27: return variant == 0 ? OD_ST(64, 128, 64, 3, 2, 2, 1, 4, true, 1) : variant == 1 ? OD_ST(64, 128, 64, 3, 2, 2, 3, 4, true, 1) : nullptr;
+    default: return nullptr;
+  }
+}
+#undef OD_ST
 
 // Tile choice from the measured table (profiles/r01/conv_cfg_sweep.txt; MI355X, batch-32 Darknet53 shapes).
 int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize, bool e8_ok, bool throughput) {
@@ -517,8 +535,20 @@ extern "C" int od_conv_weight_dims(int cout, int cin, int ksize, int* cout_pad, 
   return OD_OK;
 }
 
+static int od_conv2d_fwd_impl2(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, const char** kernel_name, bool dry_run,
+                               int* mtiles_out);
+
 int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, const char** kernel_name,
                        bool dry_run) {
+  return od_conv2d_fwd_impl2(ctx, d, stream, kernel_name, dry_run, nullptr);
+}
+
+static int od_conv2d_fwd_rows_impl(od_ctx* ctx, const od_conv_desc* d, int* rows) {
+  return od_conv2d_fwd_impl2(ctx, d, nullptr, nullptr, true, rows);
+}
+
+static int od_conv2d_fwd_impl2(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, const char** kernel_name, bool dry_run,
+                               int* mtiles_out) {
   OD_REQUIRE(ctx && d, "od_conv2d_fwd: null ctx/desc");
   OD_REQUIRE(d->x && d->w && d->scale && d->bias && d->out, "od_conv2d_fwd: null tensor");
   OD_REQUIRE(d->ksize == 1 || d->ksize == 3, "od_conv2d_fwd: ksize %d unsupported", d->ksize);
@@ -545,14 +575,29 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
              "od_conv2d_fwd: tensor too large for 32-bit element offsets");
   const int M = (int)M64;
 
+  const bool want_stats = d->bn_partials != nullptr;
+  if (want_stats)
+    OD_REQUIRE(!tconv && d->out_dtype == OD_DT_F16 && d->act == OD_ACT_LINEAR && d->res_mode == OD_RES_NONE,
+               "od_conv2d_fwd: bn_partials needs the raw convolution (f16 output, no activation, no residual, no transposed "
+               "gather; scale / bias are NOT applied)");
   int cfg = d->tile_cfg;
-  if (cfg < 0)
+  if (cfg < 0)  // (the 8-wave kernel has its own epilogue without the statistics path: not offered when they are asked for)
     cfg = pick_cfg(ctx, M, d->Cin, d->Cout, d->ksize,
-                   !tconv && (long long)d->B * d->H * d->W * d->Cin * 2 < 0x7F000000LL, cfg == -2);
+                   !want_stats && !tconv && (long long)d->B * d->H * d->W * d->Cin * 2 < 0x7F000000LL, cfg == -2);
+  if (want_stats && d->tile_cfg < 0) {
+    const int var = d->ksize == 1 ? 0 : ((d->Cin % g_cfgs[cfg].BK) == 0 ? 1 : 2);
+    if (!stats_kernel(cfg, var)) {  // same tile shape without the feature the table lacks, else the generic 128 x 128 / 64 x 128
+      const int bm = g_cfgs[cfg].BM, bn = g_cfgs[cfg].BN;
+      cfg = (d->Cin % 64 == 0) ? ((bm >= 128 && bn >= 128) ? 13 : (bn >= 128 ? 27 : 3)) : ((bm >= 128 && bn >= 128) ? 0 : (bn >= 128 ? 2 : (bm >= 128 ? 1 : 3)));
+    }
+  }
   const int cfg_pw = kNumCfgs + od_conv_win_num_cfgs(), cfg_e8 = cfg_pw + 1;
   OD_REQUIRE(cfg < cfg_e8 + od_conv_8ph_num_cfgs(), "od_conv2d_fwd: tile_cfg %d out of range", cfg);
   const bool use_pw = cfg == cfg_pw;
   const bool use_e8 = cfg >= cfg_e8;
+  const bool use_win_ = cfg >= kNumCfgs && cfg < cfg_e8;
+  OD_REQUIRE(!(want_stats && (use_e8 || use_win_)),
+             "od_conv2d_fwd: bn_partials is supported by the table kernels only (tile_cfg %d)", cfg);
   const bool use_win = cfg >= kNumCfgs && !use_pw && !use_e8;
   OD_REQUIRE(!tconv || !(use_win || use_pw || use_e8), "od_conv2d_fwd: transposed mode runs on the table kernels only (tile_cfg %d)", cfg);
   TileCfg tc = g_cfgs[(use_win || use_pw || use_e8) ? 0 : cfg];
@@ -584,6 +629,7 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
   p.alpha = d->alpha;
   p.res_mode = d->res_mode;
   p.out_f32 = d->out_dtype == OD_DT_F32;
+  p.stats = d->bn_partials;
   p.x_bytes = (unsigned)((long long)d->B * d->H * d->W * d->Cin * 2);
   p.w_bytes = (unsigned)((long long)od_round_up(d->Cout, 256) * p.Kstride * 2);
   p.obs = d->out_batch_stride ? d->out_batch_stride : (long long)p.HoWo * d->Cout;
@@ -664,12 +710,21 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
     p.M = p.mtiles * tc.BM;
   }
   p.ntiles = od_ceil_div(d->Cout, tc.BN);
+  if (mtiles_out) *mtiles_out = p.mtiles;
   // split-K for layers that cannot fill the chip with output tiles (batch-1 inference): every K-range workgroup writes
   // its partial tile to its own slab of the caller's f32 workspace; splitk == 0 lets the library choose
   p.splitk = 1;
   p.steps_per_split = 0;
   p.ws = (float*)d->splitk_workspace;
-  if (d->splitk_workspace && d->splitk != 1 && !tconv) {  // transposed mode orders its rows by parity class: no slabs
+  if (want_stats && !dry_run) {
+    const long long need = (long long)p.mtiles * 2 * d->Cout * 4;
+    if (d->bn_partials_bytes < need) {
+      od_set_error("od_conv2d_fwd: bn_partials holds %lld bytes, %d rows x 2 x %d channels need %lld", (long long)d->bn_partials_bytes,
+                   p.mtiles, d->Cout, need);
+      return OD_ERR_WORKSPACE;
+    }
+  }
+  if (d->splitk_workspace && d->splitk != 1 && !tconv && !want_stats) {  // transposed mode orders its rows by parity class: no slabs
     const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
     const int tiles = p.mtiles * p.ntiles;
     const int nk = od_ceil_div(p.Ktot, tc.BK);
@@ -698,6 +753,13 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
     return OD_ERR_INVALID;
   }
   const void* fn = use_e8 ? e8.fn : (variant == 0 ? tc.k1 : (variant == 1 ? tc.k3 : tc.k3g));
+  if (want_stats) {
+    fn = stats_kernel(cfg, variant);
+    if (!fn) {
+      od_set_error("od_conv2d_fwd: tile_cfg %d has no bn_partials instantiation for this layer (have: 0-3, 13, 14, 24, 27)", cfg);
+      return OD_ERR_INVALID;
+    }
+  }
   if (kernel_name) *kernel_name = use_e8 ? e8.name : (variant == 0 ? tc.name1 : (variant == 1 ? tc.name3 : tc.name3g));
   if (dry_run) return OD_OK;
 
@@ -719,4 +781,13 @@ int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, c
 
 extern "C" int od_conv2d_fwd(od_ctx* ctx, const od_conv_desc* d, void* stream) {
   return od_conv2d_fwd_impl(ctx, d, (hipStream_t)stream, nullptr, false);
+}
+
+extern "C" int od_conv2d_fwd_bn_rows(od_ctx* ctx, const od_conv_desc* d) {
+  if (!ctx || !d) return -1;
+  od_conv_desc q = *d;
+  if (!q.bn_partials) q.bn_partials = (float*)(uintptr_t)16;  // dry run: only the tile choice matters
+  int rows = 0;
+  if (od_conv2d_fwd_rows_impl(ctx, &q, &rows) != OD_OK) return -1;
+  return rows;
 }

@@ -585,6 +585,17 @@ extern "C" int od_bn_stats(od_ctx* ctx, const void* z, long long M, int C, const
   return OD_OK;
 }
 
+extern "C" int od_bn_stats_from_partials(od_ctx* ctx, const float* partials, int rows, long long M, int C, const float* gamma,
+                                         const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
+                                         float* run_mean, float* run_var, float momentum, void* stream) {
+  OD_REQUIRE(ctx && partials && gamma && beta && mean && rstd && scale && shift, "od_bn_stats_from_partials: null argument");
+  OD_REQUIRE(rows > 0 && M > 0 && C > 0 && C % 8 == 0, "od_bn_stats_from_partials: bad dims");
+  hipLaunchKernelGGL(od_chan_final<0>, dim3(od_ceil_div(C, 8)), dim3(256), 0, (hipStream_t)stream, partials, rows, C,
+                     1.f / (float)M, eps, gamma, beta, mean, rstd, scale, shift, run_mean, run_var, momentum);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
 extern "C" int od_scale_act(od_ctx* ctx, const void* z, const float* scale, const float* shift, const void* res,
                             int res_mode, void* y, int B, int H, int W, int C, int act, float alpha, void* stream) {
   OD_REQUIRE(ctx && z && scale && shift && y, "od_scale_act: null argument");

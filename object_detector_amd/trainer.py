@@ -140,6 +140,14 @@ class Trainer:
         mxc = max(self.lib.od_bn_workspace_bytes(self.B * (n.H // n.stride) * (n.W // n.stride), n.Cout) + 2 * n.Cout * 4
                   for n in self.nodes)
         self.bn_ws = torch.empty(mxc, dtype=torch.uint8, device=dev)
+        # BatchNorm statistics from the conv epilogue (od_conv_desc.bn_partials): one partial row per m-tile, at most M / 64
+        # rows of 2 x Cout floats.  OFF by default: measured neutral (profiles/r02/train_bn_stats_fusion.txt: the separate
+        # pass reads z hot out of L2 / MALL for 0.46 ms per step; the epilogue sums + more partial rows + giving up the
+        # 8-wave kernel for those layers cost 0.5 ms).  OD_TRAIN_FUSE_BN_STATS=1 turns it on.
+        self.fuse_bn_stats = os.environ.get("OD_TRAIN_FUSE_BN_STATS", "0") == "1"
+        self._bn_rows = {}
+        mxp = max(((self.B * (n.H // n.stride) * (n.W // n.stride) + 63) // 64) * 2 * n.Cout for n in self.nodes)
+        self.bn_part = torch.empty(mxp, dtype=torch.float32, device=dev)
 
     # ------------------------------------------------------------------------------------------------------------
     def _make_buckets(self, min_elems):
@@ -266,7 +274,7 @@ class Trainer:
         assert off == self.P
 
     # ------------------------------------------------------------------------------------------------------------
-    def _conv_raw(self, n, x, out, out_f32=False, obs=0, ops=0, bias=None):
+    def _conv_raw(self, n, x, out, out_f32=False, obs=0, ops=0, bias=None, bn_partials=None):
         d = _lib.ConvDesc()
         d.x, d.w = x.data_ptr(), self.wf[n.name].data_ptr()
         d.scale, d.bias = self.ones.data_ptr(), (bias if bias is not None else self.zeros).data_ptr()
@@ -275,7 +283,15 @@ class Trainer:
         d.act, d.res_mode, d.tile_cfg = _lib.OD_ACT_LINEAR, _lib.OD_RES_NONE, self.fwd_tile_cfg
         d.out_dtype = _lib.OD_DT_F32 if out_f32 else _lib.OD_DT_F16
         d.out_batch_stride, d.out_pix_stride = obs, ops
+        if bn_partials is not None:  # BatchNorm partial sums from the conv epilogue (no separate pass over z)
+            d.bn_partials, d.bn_partials_bytes = bn_partials.data_ptr(), bn_partials.numel() * 4
+            rows = self._bn_rows.get(n)
+            if rows is None:
+                rows = self._bn_rows[n] = self.lib.od_conv2d_fwd_bn_rows(self.ctx.handle, C.byref(d))
+                if rows <= 0 or rows * 2 * n.Cout > bn_partials.numel():
+                    raise _lib.OdError(f"bn_partials too small for {n.name}: {rows} rows")
         _lib.check(self.lib.od_conv2d_fwd(self.ctx.handle, C.byref(d), _stream_ptr()), f"conv fwd {n.name}")
+        return self._bn_rows.get(n) if bn_partials is not None else None
 
     def forward(self, x_u8):
         """uint8 [B,H,W,3] (device) -> pred f32 [B,P,C]; keeps z / statistics of every layer for the backward pass."""
@@ -300,14 +316,23 @@ class Trainer:
                                ops=n.Cout, bias=bias)
                 continue
             else:
-                self._conv_raw(n, x, n.z)
+                rows = self._conv_raw(n, x, n.z, bn_partials=self.bn_part if self.fuse_bn_stats else None)
             M = n.z.numel() // n.Cout
-            wsb = lib.od_bn_workspace_bytes(M, n.Cout)
-            _lib.check(lib.od_bn_stats(h, n.z.data_ptr(), M, n.Cout, self.view(self.params, n.name, "gamma").data_ptr(),
-                                       self.view(self.params, n.name, "beta").data_ptr(), W.BN_EPS, n.mean.data_ptr(),
-                                       n.rstd.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
-                                       self.run_mean[n.name].data_ptr(), self.run_var[n.name].data_ptr(), BN_MOMENTUM,
-                                       self.bn_ws.data_ptr(), wsb, s), "od_bn_stats")
+            if not n.first and self.fuse_bn_stats:
+                _lib.check(lib.od_bn_stats_from_partials(h, self.bn_part.data_ptr(), rows, M, n.Cout,
+                                                         self.view(self.params, n.name, "gamma").data_ptr(),
+                                                         self.view(self.params, n.name, "beta").data_ptr(), W.BN_EPS,
+                                                         n.mean.data_ptr(), n.rstd.data_ptr(), n.scale.data_ptr(),
+                                                         n.shift.data_ptr(), self.run_mean[n.name].data_ptr(),
+                                                         self.run_var[n.name].data_ptr(), BN_MOMENTUM, s),
+                           "od_bn_stats_from_partials")
+            else:
+                wsb = lib.od_bn_workspace_bytes(M, n.Cout)
+                _lib.check(lib.od_bn_stats(h, n.z.data_ptr(), M, n.Cout, self.view(self.params, n.name, "gamma").data_ptr(),
+                                           self.view(self.params, n.name, "beta").data_ptr(), W.BN_EPS, n.mean.data_ptr(),
+                                           n.rstd.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
+                                           self.run_mean[n.name].data_ptr(), self.run_var[n.name].data_ptr(), BN_MOMENTUM,
+                                           self.bn_ws.data_ptr(), wsb, s), "od_bn_stats")
             y = self.tensors[n.out]
             res = self.tensors[n.res] if n.res else None
             rm = {"none": 0, "same": 1, "up2": 2}[n.res_mode]

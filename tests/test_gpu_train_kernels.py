@@ -224,3 +224,68 @@ def test_weight_gradient_slab_path_many_splits(cuda, case):
     print(f"{case}: {sp} splits")
     assert np.array_equal(outs[0], outs[1])
     np.testing.assert_allclose(outs[0], ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 128, 3, 1), (2, 16, 16, 32, 64, 3, 2), (3, 10, 10, 128, 64, 1, 1),
+                                  (4, 40, 40, 128, 256, 3, 1), (2, 12, 12, 256, 208, 3, 1), (32, 10, 10, 512, 1024, 3, 1),
+                                  (1, 6, 6, 24, 16, 3, 1), (2, 20, 20, 512, 256, 1, 1)], ids=str)
+def test_bn_statistics_from_the_conv_epilogue(cuda, case):
+    """od_conv_desc.bn_partials: the raw convolution's epilogue writes per-m-tile partial sums of the f16 values it stores, and
+    od_bn_stats_from_partials turns them into the SAME mean / rstd / scale / shift as the separate od_bn_stats pass over z
+    (sums of the same f16 values in another fixed order: equal to f32 rounding), z itself bit-identical to the plain launch;
+    two runs are bit-identical."""
+    import ctypes as C
+    from object_detector_amd import _lib, weights as W
+    from object_detector_amd.net import Context, pack_conv_weight
+    B, H, Wd, Cin, Cout, k, stride = case
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.normal(0, 1, (B, H, Wd, Cin)).astype(np.float16)).to(cuda)
+    w = (rng.normal(0, 1, (Cout, k, k, Cin)) * np.sqrt(2.0 / (k * k * Cin))).astype(np.float16).astype(np.float32)
+    wp = torch.from_numpy(pack_conv_weight(w)).to(cuda)
+    ones, zeros = torch.ones(wp.shape[0], device=cuda), torch.zeros(wp.shape[0], device=cuda)
+    ctx = Context.get(cuda)
+    lib, h = ctx.lib, ctx.handle
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    Ho, Wo = H // stride, Wd // stride
+    M = B * Ho * Wo
+
+    def desc(out, part):
+        d = _lib.ConvDesc()
+        d.x, d.w, d.scale, d.bias, d.out = x.data_ptr(), wp.data_ptr(), ones.data_ptr(), zeros.data_ptr(), out.data_ptr()
+        d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride = B, H, Wd, Cin, Cout, k, stride
+        d.act, d.res_mode, d.out_dtype, d.tile_cfg, d.splitk = _lib.OD_ACT_LINEAR, _lib.OD_RES_NONE, _lib.OD_DT_F16, -1, 1
+        if part is not None:
+            d.bn_partials, d.bn_partials_bytes = part.data_ptr(), part.numel() * 4
+        return d
+    z0 = torch.empty((B, Ho, Wo, Cout), dtype=torch.float16, device=cuda)
+    _lib.check(lib.od_conv2d_fwd(h, C.byref(desc(z0, None)), s))
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, Cout).astype(np.float32)).to(cuda)
+    beta = torch.from_numpy(rng.normal(0, 0.1, Cout).astype(np.float32)).to(cuda)
+    ref = [torch.empty(Cout, device=cuda) for _ in range(4)]
+    ws = torch.empty(lib.od_bn_workspace_bytes(M, Cout), dtype=torch.uint8, device=cuda)
+    if Cout % 8 == 0:
+        _lib.check(lib.od_bn_stats(h, z0.data_ptr(), M, Cout, gamma.data_ptr(), beta.data_ptr(), W.BN_EPS, *(t.data_ptr() for t in ref),
+                                   None, None, 0.99, ws.data_ptr(), ws.numel(), s))
+    outs = []
+    for _ in range(2):
+        part = torch.full((((M + 63) // 64) * 2 * Cout,), float("nan"), dtype=torch.float32, device=cuda)
+        z1 = torch.empty_like(z0)
+        d = desc(z1, part)
+        rows = lib.od_conv2d_fwd_bn_rows(h, C.byref(d))
+        assert 0 < rows <= (M + 63) // 64
+        _lib.check(lib.od_conv2d_fwd(h, C.byref(d), s))
+        got = [torch.empty(Cout, device=cuda) for _ in range(4)]
+        _lib.check(lib.od_bn_stats_from_partials(h, part.data_ptr(), rows, M, Cout, gamma.data_ptr(), beta.data_ptr(), W.BN_EPS,
+                                                 *(t.data_ptr() for t in got), None, None, 0.99, s))
+        torch.cuda.synchronize()
+        assert torch.equal(z1, z0)
+        assert torch.isfinite(part[:rows * 2 * Cout]).all()
+        outs.append([t.cpu().numpy() for t in got])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    zf = z0.float().cpu().numpy().reshape(M, Cout).astype(np.float64)
+    mu, var = zf.mean(0), zf.var(0)
+    np.testing.assert_allclose(outs[0][0], mu, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(outs[0][1], 1 / np.sqrt(var + W.BN_EPS), rtol=2e-4)
+    for a, r in zip(outs[0], ref):
+        np.testing.assert_allclose(a, r.cpu().numpy(), rtol=2e-4, atol=2e-5)
