@@ -113,7 +113,10 @@ static __device__ __forceinline__ void conv_epilogue(const ConvKP& p, char* smem
   }
   // residual rows are fetched up front (one 16-B load per store pass, all in flight together) so that their HBM/L2
   // latency overlaps the LDS staging instead of serialising pass after pass
-  constexpr int NPASS = WTM / RPP;
+  // a wave-row of the tile (WTM rows) is stored in passes of RPP rows; a workgroup with more threads than one wave-row has
+  // 8-channel chunks (512 threads on a 64 x 64 tile: RPP = 64 > WTM = 32) makes ONE pass in which only rows < WTM take part
+  constexpr int NPASS = (WTM + RPP - 1) / RPP;
+  constexpr bool RAGGED = (WTM % RPP) != 0;
   f16x8 resv[WM][NPASS];
   if (p.res_mode != OD_RES_NONE && p.splitk <= 1) {
 #pragma unroll
@@ -122,6 +125,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvKP& p, char* smem
       for (int ps = 0; ps < NPASS; ++ps) {
         int m = m0 + wr * WTM + ps * RPP + tid / CH;
         f16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (RAGGED && ps * RPP + tid / CH >= WTM) m = p.M;
         if (p.tconv && m < p.M) m = od_tconv_pixel(p, (unsigned)m, WM * MT * 16);
         if (m >= 0 && m < p.M && n < p.Cout) {
           long long roff;
@@ -157,7 +161,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvKP& p, char* smem
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
         const int row = ps * RPP + tid / CH;
-        const int m = m0 + wr * WTM + row;
+        const int m = (RAGGED && row >= WTM) ? p.M : m0 + wr * WTM + row;
         if (m < p.M && n < p.Cout) {
           float* o = slab + (long long)m * p.Cout + n;
           *(f32x4*)o = *(const f32x4*)(stg + row * SLD + c8);
@@ -170,7 +174,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvKP& p, char* smem
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int row = ps * RPP + tid / CH;
-      int m = m0 + wr * WTM + row;
+      int m = (RAGGED && row >= WTM) ? p.M : m0 + wr * WTM + row;
       if (p.tconv && m < p.M) m = od_tconv_pixel(p, (unsigned)m, WM * MT * 16);
       if (m >= 0 && m < p.M && n < p.Cout) {
         const f32x4 v0 = *(const f32x4*)(stg + row * SLD + c8);

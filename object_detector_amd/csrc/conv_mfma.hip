@@ -470,11 +470,13 @@ int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize, bool e8_ok,
   const bool spec_ok = (Cin % 64) == 0;  // wave-specialised kernels are tap-uniform only
   if (Cout <= 64) return (ksize == 3 && od_ceil_div(M, 128) >= 8 * cus) ? 1 : 3;
   const long t128 = (long)od_ceil_div(M, 128) * od_ceil_div(Cout, 128);
-  // small-M layers, measured IN the network (scripts/sweep_net_cfg.py, profiles/r01/conv_innet_sweep.txt): their input
-  // was just written by the previous kernel, every first touch misses L2, so ring depth matters more than in a
-  // back-to-back microbenchmark -- 3-deep specialised 64x128 (27) for M <= 16 k, 4-deep 64x64 (24) for long-K 1x1 at M <= 4 k
   if (ksize == 1) {
     if (!spec_ok) return 3;
+    // small-M layers, measured IN the network (scripts/sweep_net_cfg.py, profiles/r01/conv_innet_sweep.txt): their input
+    // was just written by the previous kernel, every first touch misses L2, so ring depth matters more than in a
+    // back-to-back microbenchmark -- 3-deep specialised 64x128 (27) for M <= 16 k, 4-deep 64x64 (24) for long-K 1x1 at M <= 4 k.
+    // (Round 2 tried a SPECIALISED 64 x 64 tile -- 4 MFMA + 4 DMA waves -- for these short-K layers: slower than the plain
+    // one on every 1x1 shape, 15.9 vs 13.0 us on s3.a; profiles/r02/spec64_sweep.txt.)
     if (M <= 4096) return (M >= 2048 && Cin >= 512) ? 24 : 3;
     if (M <= 16384) return 27;
     if (Cout < 256) return 3;
