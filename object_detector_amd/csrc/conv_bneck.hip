@@ -51,9 +51,13 @@ static __device__ __forceinline__ int bn_swz(int row) {
   return CPR == 16 ? ((row & 7) << 1) : (CPR == 8 ? (row & 7) : 3 * ((row >> 2) & 1));
 }
 
-static __device__ __forceinline__ float bn_act(float v, int act, float alpha) {
-  if (act == OD_ACT_LEAKY) return od_leaky(v, alpha);
-  if (act == OD_ACT_ELU) return v > 0.f ? v : alpha * od_expm1_fast(v);
+// The activation is a TEMPLATE parameter of the kernels: as a run-time enum tested per element (round 1) the compiler kept
+// the dispatch as control flow inside the unrolled epilogues -- 328 branches and 40 v_exp_f32 in od_bneck<64>, the ELU path
+// with its divergent v > 0 test laid out for every element even when the network only ever asks for LeakyReLU.
+template <int ACT>
+static __device__ __forceinline__ float bn_act(float v, float alpha) {
+  if (ACT == OD_ACT_LEAKY) return od_leaky(v, alpha);
+  if (ACT == OD_ACT_ELU) return v > 0.f ? v : alpha * od_expm1_fast(v);
   return v;
 }
 
@@ -104,7 +108,7 @@ __device__ unsigned long long g_bn_stamps[2][8];
 // Stamps of the 8-wave version: producer 3.8 k, window DMA issue 4.8 k (the issuing waves stall while the memory pipeline
 // is full: 41 KB per tile at the CU's HBM share), consumer 2.0 k, epilogue 4.5 k cycles per tile, all in series; with
 // loader waves the 4.8 k run beside the other 10.3 k.
-template <int C, int DBG = 0>
+template <int C, int DBG = 0, int ACT = OD_ACT_LEAKY>
 __global__ __launch_bounds__(C == 64 ? 768 : 512, C == 64 ? 3 : 2) void od_bneck(BneckKP p, int ntiles) {
   using Cf = BneckCfg<C>;
   constexpr bool LOADERS = (C == 64);
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(C == 64 ? 768 : 512, C == 64 ? 3 : 2) void od_bneck
             f16x4 h;
   #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float v = bn_act(acc1[j][e] * sc1[j][e] + bi1[j][e], p.act, p.alpha);
+              const float v = bn_act<ACT>(acc1[j][e] * sc1[j][e] + bi1[j][e], p.alpha);
               h[e] = inside ? (f16)v : (f16)0.f;
             }
             const int lc = j * 2 + (lq >> 1);
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(C == 64 ? 768 : 512, C == 64 ? 3 : 2) void od_bneck
         }
         f16x8 h;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) h[e] = (f16)(bn_act(v[e] * sc[e] + bi[e], p.act, p.alpha) + (float)r[e]);
+        for (int e = 0; e < 8; ++e) h[e] = (f16)(bn_act<ACT>(v[e] * sc[e] + bi[e], p.alpha) + (float)r[e]);
         *(f16x8*)(p.out + ((long long)(b * p.H + y0 + ty) * p.W + x0 + l15) * C + ch) = h;
       }
     }
@@ -454,7 +458,7 @@ extern "C" int od_bottleneck_supported(int H, int W, int C) {
   return (C == 64 || C == 128) && H > 0 && W > 0 && (H % 16) == 0 && (W % 16) == 0;
 }
 
-const char* od_bottleneck_kernel_name(int C) { return C == 64 ? "od_bneck<64, 0>" : "od_bneck<128, 0>"; }
+const char* od_bottleneck_kernel_name(int C) { return C == 64 ? "od_bneck<64, 0, 1>" : "od_bneck<128, 0, 1>"; }
 
 extern "C" int od_bottleneck_fwd(od_ctx* ctx, const od_bneck_desc* d, void* stream) {
   OD_REQUIRE(ctx && d, "od_bottleneck_fwd: null ctx/desc");
@@ -489,8 +493,17 @@ extern "C" int od_bottleneck_fwd(od_ctx* ctx, const od_bneck_desc* d, void* stre
     const char* e = getenv("OD_CONV_DEBUG");
     dbg = e ? atoi(e) : 0;
   }
-  const void* fn = d->C == 64 ? (dbg == 32 ? (const void*)&od_bneck<64, 1> : (const void*)&od_bneck<64>)
-                              : (const void*)&od_bneck<128>;
+  const void* fn;
+  if (d->C == 64) {
+    fn = dbg == 32 && d->act == OD_ACT_LEAKY ? (const void*)&od_bneck<64, 1, OD_ACT_LEAKY>
+         : d->act == OD_ACT_LEAKY            ? (const void*)&od_bneck<64, 0, OD_ACT_LEAKY>
+         : d->act == OD_ACT_ELU              ? (const void*)&od_bneck<64, 0, OD_ACT_ELU>
+                                             : (const void*)&od_bneck<64, 0, OD_ACT_LINEAR>;
+  } else {
+    fn = d->act == OD_ACT_LEAKY ? (const void*)&od_bneck<128, 0, OD_ACT_LEAKY>
+         : d->act == OD_ACT_ELU ? (const void*)&od_bneck<128, 0, OD_ACT_ELU>
+                                : (const void*)&od_bneck<128, 0, OD_ACT_LINEAR>;
+  }
   const int lds = d->C == 64 ? BneckCfg<64>::LDS_BYTES : BneckCfg<128>::LDS_BYTES;
   if (int rc = od_ensure_lds(ctx, fn, (size_t)lds)) return rc;
   int ntiles = d->B * p.tiles_x * p.tiles_y;

@@ -60,9 +60,11 @@ constexpr int S_UROUNDS = (S_UW * S_UW * 3 + 511) / 512;  // byte loads per thre
 
 static __device__ __forceinline__ int s_swz(int row) { return 3 * ((row >> 2) & 1); }
 
-static __device__ __forceinline__ float s_act(float v, int act, float alpha) {
-  if (act == OD_ACT_LEAKY) return od_leaky(v, alpha);
-  if (act == OD_ACT_ELU) return v > 0.f ? v : alpha * od_expm1_fast(v);
+// compile-time activation: see conv_bneck.hip bn_act (405 branches and 48 v_exp_f32 in the run-time-enum form of od_stem)
+template <int ACT>
+static __device__ __forceinline__ float s_act(float v, float alpha) {
+  if (ACT == OD_ACT_LEAKY) return od_leaky(v, alpha);
+  if (ACT == OD_ACT_ELU) return v > 0.f ? v : alpha * od_expm1_fast(v);
   return v;
 }
 
@@ -73,7 +75,15 @@ static __device__ __forceinline__ void s_buffer_dma(__amdgpu_buffer_rsrc_t rs, i
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
 
-__global__ __launch_bounds__(512, 2) void od_stem(StemKP p, int ntiles) {
+// DBG = 1 (OD_CONV_DEBUG=64): s_memtime stamps of the 6th tile of workgroup 0, waves 0 and 5 (od_debug_stem_stamps)
+__device__ unsigned long long g_stem_stamps[2][8];
+#define ST_STAMP(k)                                                                         \
+  do {                                                                                      \
+    if (DBG) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[k])::"memory"); \
+  } while (0)
+
+template <int DBG, int ACT = OD_ACT_LEAKY>
+__global__ __launch_bounds__(512, 2) void od_stem_k(StemKP p, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -169,8 +179,11 @@ __global__ __launch_bounds__(512, 2) void od_stem(StemKP p, int ntiles) {
   __syncthreads();
 
   int cur = 0;
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int tcount = 0;
 #pragma unroll 1
   for (; tile < ntiles; tile += (int)gridDim.x) {
+    ST_STAMP(0);
     const int b = tile / tpi;
     const int trem = tile - b * tpi;
     const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
@@ -178,42 +191,66 @@ __global__ __launch_bounds__(512, 2) void od_stem(StemKP p, int ntiles) {
     const char* uw = smem + S_OFF_U + cur * S_UBYTES;
 
     // ---- producer: the 33x33 window of first-layer pixels ----------------------------------------------------------
-#pragma unroll 1
-    for (int f = wave; f < S_NTF; f += 8) {
-      const int wp = f * 16 + l15;
+    // Two m-fragments per trip, written out by hand (the optimizer refuses to unroll this loop): the LDS reads and MFMAs of
+    // the second fragment are in flight while the VALU epilogue of the first one issues.  With two waves per SIMD the
+    // one-fragment form spent ~1.1 k cycles per fragment on ~80 VALU instructions: latency, not VALU throughput.
+    typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+    auto p_load = [&](int f, int& wp, int& wy, int& wx, f16x8& xf, f16x8& xg) {
+      wp = f * 16 + l15;
       const int wpc = wp < S_NTP ? wp : S_NTP - 1;
-      const int wy = wpc / S_TW, wx = wpc - wy * S_TW;
+      wy = wpc / S_TW;
+      wx = wpc - wy * S_TW;
       const char* pbase = uw + (wy * S_UW + wx) * 8;
-      typedef f16 f16x4 __attribute__((ext_vector_type(4)));
       const f16x4 q0 = *(const f16x4*)(pbase + ko0), q1 = *(const f16x4*)(pbase + ko1);
       const f16x4 q8 = *(const f16x4*)(pbase + ko8);
-      const f16x8 xf = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+      xf = f16x8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
       const f16 z = (f16)0.f;
-      const f16x8 xg = lq == 0 ? f16x8{q8[0], q8[1], q8[2], q8[3], z, z, z, z} : f16x8{z, z, z, z, z, z, z, z};
-      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+      xg = lq == 0 ? f16x8{q8[0], q8[1], q8[2], q8[3], z, z, z, z} : f16x8{z, z, z, z, z, z, z, z};
+    };
+    auto p_mfma = [&](const f16x8& xf, const f16x8& xg, f32x4& a0, f32x4& a1) {
+      a0 = f32x4{0.f, 0.f, 0.f, 0.f};
+      a1 = f32x4{0.f, 0.f, 0.f, 0.f};
       a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfa[0], xf, a0, 0, 0, 0);
       a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfa[1], xf, a1, 0, 0, 0);
       a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfb[0], xg, a0, 0, 0, 0);
       a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfb[1], xg, a1, 0, 0, 0);
+    };
+    auto p_store = [&](int wp, int wy, int wx, const f32x4& a0, const f32x4& a1) {
       if (wp < S_NTP) {
         const int iy = 2 * y0 - 1 + wy, ix = 2 * x0 - 1 + wx;
         const bool inside = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         f16x8 h;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v0 = s_act(a0[e] * sc0[e] + bi0[e], p.act, p.alpha);
-          const float v1 = s_act(a1[e] * sc0[4 + e] + bi0[4 + e], p.act, p.alpha);
+          const float v0 = s_act<ACT>(a0[e] * sc0[e] + bi0[e], p.alpha);
+          const float v1 = s_act<ACT>(a1[e] * sc0[4 + e] + bi0[4 + e], p.alpha);
           h[e] = inside ? (f16)v0 : (f16)0.f;
           h[4 + e] = inside ? (f16)v1 : (f16)0.f;
         }
         const int trow = wy * S_TROW + (wx & 1) * 17 + (wx >> 1);  // de-interleaved columns
         *(f16x8*)(smem + S_OFF_T + trow * 64 + ((lq ^ s_swz(trow)) * 16)) = h;
       }
+    };
+#pragma unroll 1
+    for (int f = wave; f < S_NTF; f += 16) {
+      int wpA, wyA, wxA, wpB, wyB, wxB;
+      f16x8 xfA, xgA, xfB, xgB;
+      f32x4 a0A, a1A, a0B, a1B;
+      const bool hasB = f + 8 < S_NTF;  // wave-uniform
+      p_load(f, wpA, wyA, wxA, xfA, xgA);
+      if (hasB) p_load(f + 8, wpB, wyB, wxB, xfB, xgB);
+      p_mfma(xfA, xgA, a0A, a1A);
+      if (hasB) p_mfma(xfB, xgB, a0B, a1B);
+      p_store(wpA, wyA, wxA, a0A, a1A);
+      if (hasB) p_store(wpB, wyB, wxB, a0B, a1B);
     }
+    ST_STAMP(1);
     __syncthreads();  // window complete; this tile's uint8 window is free
+    ST_STAMP(2);
 
     const int tnext = tile + (int)gridDim.x;
     if (tnext < ntiles) fetch_u(tnext);  // global byte loads in flight during the consumer
+    ST_STAMP(3);
 
     // ---- consumer: 3x3 stride 2 from the window ------------------------------------------------------------------
     f32x4 acc[4][2];
@@ -243,6 +280,7 @@ __global__ __launch_bounds__(512, 2) void od_stem(StemKP p, int ntiles) {
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------------------
+    ST_STAMP(4);
     od_mfma_results_ready();
     {
       const int ch = (wn * 2 + (lq & 1)) * 16 + (lq >> 1) * 8;
@@ -270,13 +308,20 @@ __global__ __launch_bounds__(512, 2) void od_stem(StemKP p, int ntiles) {
         }
         f16x8 h;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) h[e] = (f16)s_act(v[e] * sc[e] + bi[e], p.act, p.alpha);
+        for (int e = 0; e < 8; ++e) h[e] = (f16)s_act<ACT>(v[e] * sc[e] + bi[e], p.alpha);
         *(f16x8*)(p.out + ((long long)(b * Ho + y0 + ty) * Wo + x0 + l15) * 64 + ch) = h;
       }
     }
+    ST_STAMP(5);
     if (tnext < ntiles) store_u(cur ^ 1);  // waits for the byte loads issued before the consumer
+    ST_STAMP(6);
     __syncthreads();                        // next window visible; everyone is done with the first-layer window
+    ST_STAMP(7);
     cur ^= 1;
+    if (DBG && blockIdx.x == 0 && (wave == 0 || wave == 5) && ++tcount == 6 && lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g_stem_stamps[wave ? 1 : 0][k] = st[k];
+    }
   }
 }
 
@@ -284,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void od_stem(StemKP p, int ntiles) {
 
 extern "C" int od_stem_supported(int H, int W) { return H > 0 && W > 0 && (H % 32) == 0 && (W % 32) == 0; }  // net input rule
 
-const char* od_stem_kernel_name() { return "od_stem"; }
+const char* od_stem_kernel_name() { return "od_stem_k<0, 1>"; }
 
 extern "C" int od_stem_fwd(od_ctx* ctx, const od_stem_desc* d, void* stream) {
   OD_REQUIRE(ctx && d, "od_stem_fwd: null ctx/desc");
@@ -313,8 +358,22 @@ extern "C" int od_stem_fwd(od_ctx* ctx, const od_stem_desc* d, void* stream) {
   int ntiles = d->B * p.tiles_x * p.tiles_y;
   const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
   const int grid = ntiles < cus ? ntiles : cus;
-  if (int rc = od_ensure_lds(ctx, (const void*)&od_stem, (size_t)S_LDS)) return rc;
+  static int dbg = -1;
+  if (dbg < 0) {
+    const char* e = getenv("OD_CONV_DEBUG");
+    dbg = e ? atoi(e) : 0;
+  }
+  const void* fn = dbg == 64 && d->act == OD_ACT_LEAKY ? (const void*)&od_stem_k<1, OD_ACT_LEAKY>
+                   : d->act == OD_ACT_LEAKY            ? (const void*)&od_stem_k<0, OD_ACT_LEAKY>
+                   : d->act == OD_ACT_ELU              ? (const void*)&od_stem_k<0, OD_ACT_ELU>
+                                                       : (const void*)&od_stem_k<0, OD_ACT_LINEAR>;
+  if (int rc = od_ensure_lds(ctx, fn, (size_t)S_LDS)) return rc;
   void* args[] = {&p, &ntiles};
-  OD_CHECK_HIP(hipLaunchKernel((const void*)&od_stem, dim3((unsigned)grid), dim3(512), args, (size_t)S_LDS, (hipStream_t)stream));
+  OD_CHECK_HIP(hipLaunchKernel(fn, dim3((unsigned)grid), dim3(512), args, (size_t)S_LDS, (hipStream_t)stream));
   return OD_OK;
+}
+
+// debug only (not part of include/odhip.h)
+extern "C" int od_debug_stem_stamps(unsigned long long* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stem_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
 }
