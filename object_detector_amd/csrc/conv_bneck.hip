@@ -445,7 +445,7 @@ __global__ __launch_bounds__(C == 64 ? 768 : 512, C == 64 ? 3 : 2) void od_bneck
       cur ^= 1;
     }
     BN_STAMP(7);
-    if (DBG && blockIdx.x == 0 && (wave == 0 || wave == 5) && ++tcount == 6 && lane == 0) {
+    if (DBG && blockIdx.x == (Cf::RESIDENT ? 0 : 300) && (wave == 0 || wave == 5) && (++tcount == 6 || !Cf::RESIDENT) && lane == 0) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) g_bn_stamps[wave ? 1 : 0][k] = st[k];
     }
@@ -500,7 +500,8 @@ extern "C" int od_bottleneck_fwd(od_ctx* ctx, const od_bneck_desc* d, void* stre
          : d->act == OD_ACT_ELU              ? (const void*)&od_bneck<64, 0, OD_ACT_ELU>
                                              : (const void*)&od_bneck<64, 0, OD_ACT_LINEAR>;
   } else {
-    fn = d->act == OD_ACT_LEAKY ? (const void*)&od_bneck<128, 0, OD_ACT_LEAKY>
+    fn = dbg == 33 && d->act == OD_ACT_LEAKY ? (const void*)&od_bneck<128, 1, OD_ACT_LEAKY>
+         : d->act == OD_ACT_LEAKY ? (const void*)&od_bneck<128, 0, OD_ACT_LEAKY>
          : d->act == OD_ACT_ELU ? (const void*)&od_bneck<128, 0, OD_ACT_ELU>
                                 : (const void*)&od_bneck<128, 0, OD_ACT_LINEAR>;
   }

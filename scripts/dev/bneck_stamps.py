@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """s_memtime stamps of od_bneck<64> (OD_CONV_DEBUG=32 build): 6th tile of workgroup 0, waves 0 and 5."""
 import ctypes as C, os, pathlib, subprocess, sys
-os.environ["OD_CONV_DEBUG"] = "32"
+C_ = sys.argv[1] if len(sys.argv) > 1 else "64"
+os.environ["OD_CONV_DEBUG"] = "32" if C_ == "64" else "33"
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent))
 import torch
-sys.argv = [sys.argv[0], "--only", "64", "--reps", "3"]
+sys.argv = [sys.argv[0], "--only", C_, "--reps", "3"]
 import bench_bneck
 bench_bneck.main()
 from object_detector_amd.net import Context

@@ -37,6 +37,10 @@ CASES = [
     (2, 48, 32, 128, "leaky"),
     (1, 32, 32, 64, "elu"),
     (1, 32, 16, 128, None),
+    # every (C, activation) pair is its own compiled kernel since round 2 (the activation is a template parameter)
+    (2, 32, 32, 64, None),
+    (1, 16, 32, 128, "elu"),
+    (33, 32, 32, 64, "leaky"),    # 132 tiles... C = 64 is persistent: more tiles than one round of its loader / compute waves at small grids
 ]
 
 

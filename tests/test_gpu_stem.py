@@ -26,16 +26,26 @@ def _inputs(B, H, W, seed):
     return x, w0, s0, b0, w3, s3, b3
 
 
+def _actf(y, act, a):
+    if act == "leaky":
+        return _leaky(y, a)
+    if act == "elu":
+        return np.where(y > 0, y, a * np.expm1(np.minimum(y, 0)))
+    return y
+
+
+@pytest.mark.parametrize("act", ["leaky", "elu", None], ids=str)  # each activation is its own compiled kernel
 @pytest.mark.parametrize("shape", [(1, 32, 32), (2, 64, 96), (3, 96, 32), (1, 160, 64)], ids=str)
-def test_stem_matches_oracle(cuda, shape):
+def test_stem_matches_oracle(cuda, shape, act):
     from object_detector_amd import ops
     B, H, W = shape
+    a = 0.1 if act == "leaky" else 1.0
     x, w0, s0, b0, w3, s3, b3 = _inputs(B, H, W, hash(shape) & 0xFFFF)
-    out = ops.stem(torch.from_numpy(x).to(cuda), w0, s0, b0, w3, s3, b3, act="leaky", alpha=0.1)
+    out = ops.stem(torch.from_numpy(x).to(cuda), w0, s0, b0, w3, s3, b3, act=act, alpha=a)
     got = out.cpu().numpy().astype(np.float64)
     t = onet.conv_nhwc(x.astype(np.float32), w0, 1, torch.float64).astype(np.float64) * s0 + b0
-    t = _leaky(t, 0.1).astype(np.float16).astype(np.float32)
-    ref = _leaky(onet.conv_nhwc(t, w3, 2, torch.float64).astype(np.float64) * s3 + b3, 0.1)
+    t = _actf(t, act, a).astype(np.float16).astype(np.float32)
+    ref = _actf(onet.conv_nhwc(t, w3, 2, torch.float64).astype(np.float64) * s3 + b3, act, a)
     assert got.shape == ref.shape
     err = np.abs(got - ref)
     tol = 1e-3 * max(1.0, np.abs(ref).max()) + 2.0 ** -10 * np.abs(ref)
