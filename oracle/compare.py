@@ -22,7 +22,7 @@ def logit_stats(got, ref16, ref32):
     `_check_layers_in_isolation`).  The MAX difference over n logits therefore grows like sigma * sqrt(2 ln n) (78 k logits at 2 x 96^2, 14 M at
     32 x 320^2) while sigma itself does not; asserted are
       (a) sigma = rms(dev - f16 oracle) <= 3e-4 of the logit scale,
-      (b) no outliers: max <= sigma * (sqrt(2 ln n) + 2.5)  (a wrong tile / race shows up here),
+      (b) no outliers: max <= sigma * (sqrt(2 ln n) + 3)  (a wrong tile / race shows up here),
       (c) the device is as close to the plain fp32 oracle as the CPU f16-storage run is: rms ratio <= 1.15."""
     scale = max(1.0, float(np.abs(ref32).max()))
     d = (got - ref16).astype(np.float64)
@@ -45,6 +45,6 @@ def assert_logits(rec, tag):
           f"{rec['max_over_sigma']:.1f} (gaussian {rec['gaussian_max_over_sigma']:.1f}); vs fp32 oracle: rms dev "
           f"{rec['rms_dev_vs_fp32']:.3e} / cpu-f16 {rec['rms_f16oracle_vs_fp32']:.3e}")
     assert rec["rms_rel_scale"] <= 3e-4, rec
-    assert rec["max_over_sigma"] <= rec["gaussian_max_over_sigma"] + 2.5, rec
+    assert rec["max_over_sigma"] <= rec["gaussian_max_over_sigma"] + 3.0, rec
     assert rec["rms_dev_vs_fp32"] <= 1.15 * rec["rms_f16oracle_vs_fp32"], rec
     assert rec["max_dev_vs_fp32"] <= 2e-2 * rec["logit_scale"], rec
