@@ -122,8 +122,13 @@ class Net:
         # group of layers costs inside the running pipeline (scripts/dev/exp_ablate.sh); never set in tests / bench lines
         abl = [q.partition("*") for q in filter(None, os.environ.get("OD_ABLATE_OPS", "").split(","))]
         if abl:
+            seen, occ = {}, []
+            for inf in self.op_info:  # "name#k" = the k-th launch of a layer that runs once per pyramid level
+                occ.append(f'{inf["name"]}#{seen.get(inf["name"], 0)}')
+                seen[inf["name"]] = seen.get(inf["name"], 0) + 1
             keep = [i for i, inf in enumerate(self.op_info)
-                    if not any(inf["name"].startswith(pre) and inf["name"].endswith(suf) for pre, _s, suf in abl)]
+                    if not any((inf["name"].startswith(pre) and inf["name"].endswith(suf)) or occ[i] == pre + _s + suf
+                               for pre, _s, suf in abl)]
             self.ops = [self.ops[i] for i in keep]
             self.op_info = [self.op_info[i] for i in keep]
         arr = (_lib.PlanOp * len(self.ops))(*self.ops)
