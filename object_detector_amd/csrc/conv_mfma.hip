@@ -523,7 +523,16 @@ int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize, bool e8_ok,
     return pick;
   }
   if (Cout <= 256) return M < 2048 ? 3 : 27;       // few, narrow tiles (neck / prediction module on the coarse levels)
-  return 14;                                       // few tiles, long K: one deep-ring workgroup per CU
+  // few tiles, long K.  Up to half a round of 128 x 128 tiles (backward-data of stage 5: M = 3200, Cout = 512, K = 9216) the
+  // 64-row specialised tile doubles the workgroups: 55.6 vs 78.8 us (profiles/r02/dgrad_cfg_sweep.txt); above that one
+  // deep-ring workgroup per CU
+  static int last = -2;
+  if (last == -2) {
+    const char* e = getenv("OD_PICK_FEW_TILES");  // tuning: force the config of this branch
+    last = e ? atoi(e) : -1;
+  }
+  if (last >= 0) return last;
+  return (M >= 2048 && 2 * t128 <= cus) ? 27 : 14;  // (batch-1 maps keep their split-K plan on 14)
 }
 
 }  // namespace

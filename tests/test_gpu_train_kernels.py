@@ -289,3 +289,43 @@ def test_bn_statistics_from_the_conv_epilogue(cuda, case):
     np.testing.assert_allclose(outs[0][1], 1 / np.sqrt(var + W.BN_EPS), rtol=2e-4)
     for a, r in zip(outs[0], ref):
         np.testing.assert_allclose(a, r.cpu().numpy(), rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("count,nslabs", [(2048, 512), (2048, 3), (8192, 77), (73728, 20), (1179648, 3), (32768, 1),
+                                          (216 * 8, 130)], ids=str)
+def test_wgrad_slab_reduce_order_is_fixed_and_restated(cuda, count, nslabs):
+    """od_wgrad_reduce_multi: the slab range is cut into G contiguous groups (G from count and nslabs only), each group
+    is added in ascending slab order, the G partial sums in ascending group order -- restated in numpy f32, bit for bit."""
+    import ctypes as C
+    from object_detector_amd import _lib
+    from object_detector_amd.net import Context
+    rng = np.random.default_rng(count + nslabs)
+    slabs = (rng.normal(0, 1, (nslabs, count)) * 10.0 ** rng.integers(-3, 4, (nslabs, 1))).astype(np.float32)
+    n4 = count // 4
+    G = 1
+    while G < 64 and n4 * G < 65536 and G * 2 <= nslabs:
+        G *= 2
+    per = -(-nslabs // G)
+    ref = None
+    for g in range(G):
+        k0, k1 = g * per, min((g + 1) * per, nslabs)
+        if k0 >= k1:
+            break
+        part = slabs[k0].copy()
+        for k in range(k0 + 1, k1):
+            part += slabs[k]
+        ref = part if ref is None else ref + part
+    ctx = Context.get(cuda)
+    lib, h = ctx.lib, ctx.handle
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    sd = torch.from_numpy(slabs).to(cuda)
+    off = 16
+    g = torch.full((count + 2 * off,), float("nan"), dtype=torch.float32, device=cuda)
+    e = _lib.WgradRed()
+    e.dw_offset, e.count, e.slabs, e.nslabs = off, count, sd.data_ptr(), nslabs
+    tbl = torch.frombuffer(bytearray(bytes(e)), dtype=torch.uint8).to(cuda)
+    _lib.check(lib.od_wgrad_reduce_multi(h, tbl.data_ptr(), 1, g.data_ptr(), s))
+    torch.cuda.synchronize()
+    got = g.cpu().numpy()
+    assert np.isnan(got[:off]).all() and np.isnan(got[off + count:]).all()
+    assert np.array_equal(got[off:off + count], ref)
