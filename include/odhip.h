@@ -104,6 +104,20 @@ typedef struct od_conv_desc {
                          od_conv2d_fwd_bn_rows(); od_bn_stats_from_partials turns them into the batch statistics, so the
                          separate pass of od_bn_stats over z is not needed.  Needs out_dtype f16; disables split-K */
   int64_t bn_partials_bytes;
+  /* optional (w2 == NULL: none): the pointwise (1x1, stride 1) layer that consumes this launch's output, e.g. the first
+   * conv of the next residual block:   out2 = act2(scale2 * conv1x1(out, w2) + bias2),  f16 dense [B,Ho,Wo,Cout2].
+   * `out` is written as usual (f16, dense, no transposed / bn_partials).  When the selected kernel holds all channels of
+   * a pixel in one workgroup (8-wave kernel, Cout == 256, Cout2 == 128) the second layer runs in its epilogue on the
+   * rounded f16 rows -- one launch, `out` is not read back; otherwise the library issues the 1x1 as a second launch on
+   * the same stream.  Same rounding points either way.  w2 is packed like w (od_conv_weight_dims(Cout2, Cout, 1)). */
+  const void* w2;
+  const float* scale2;
+  const float* bias2;
+  void* out2;
+  int32_t Cout2;
+  int32_t act2;
+  float alpha2;
+  int32_t pad2_;
 } od_conv_desc;
 
 int od_conv_weight_dims(int cout, int cin, int ksize, int* cout_pad, int* kpad);

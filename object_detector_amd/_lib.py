@@ -32,6 +32,9 @@ class ConvDesc(C.Structure):
         ("tile_cfg", C.c_int32), ("transposed", C.c_int32), ("splitk", C.c_int32),
         ("splitk_workspace", C.c_void_p), ("splitk_workspace_bytes", C.c_int64),
         ("bn_partials", C.c_void_p), ("bn_partials_bytes", C.c_int64),
+        # the pointwise layer that consumes this launch's output (None = no second layer)
+        ("w2", C.c_void_p), ("scale2", C.c_void_p), ("bias2", C.c_void_p), ("out2", C.c_void_p),
+        ("Cout2", C.c_int32), ("act2", C.c_int32), ("alpha2", C.c_float), ("pad2_", C.c_int32),
     ]
 
 

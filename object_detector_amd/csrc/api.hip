@@ -70,7 +70,9 @@ const std::vector<StructInfo>& od_struct_table() {
         OD_F(od_conv_desc, out_dtype), OD_F(od_conv_desc, out_batch_stride), OD_F(od_conv_desc, out_pix_stride),
         OD_F(od_conv_desc, tile_cfg), OD_F(od_conv_desc, transposed), OD_F(od_conv_desc, splitk),
         OD_F(od_conv_desc, splitk_workspace), OD_F(od_conv_desc, splitk_workspace_bytes), OD_F(od_conv_desc, bn_partials),
-        OD_F(od_conv_desc, bn_partials_bytes)}},
+        OD_F(od_conv_desc, bn_partials_bytes), OD_F(od_conv_desc, w2), OD_F(od_conv_desc, scale2), OD_F(od_conv_desc, bias2),
+        OD_F(od_conv_desc, out2), OD_F(od_conv_desc, Cout2), OD_F(od_conv_desc, act2), OD_F(od_conv_desc, alpha2),
+        OD_F(od_conv_desc, pad2_)}},
       {"od_bneck_desc", sizeof(od_bneck_desc),
        {OD_F(od_bneck_desc, x), OD_F(od_bneck_desc, w1), OD_F(od_bneck_desc, scale1), OD_F(od_bneck_desc, bias1),
         OD_F(od_bneck_desc, w3), OD_F(od_bneck_desc, scale3), OD_F(od_bneck_desc, bias3), OD_F(od_bneck_desc, out),

@@ -51,9 +51,15 @@ constexpr unsigned E_OOB = 0x80000000u;  // buffer offset beyond any tensor this
 // pixel -- even lane rows get fragment j, odd rows fragment j+1 -- so scale/bias/activation/residual run in f32 on a
 // 16-byte residual load and end in one 16-byte NHWC store (one rounding to f16), 64 contiguous bytes per pixel per
 // instruction.  Same arithmetic and rounding points as conv_epilogue.
-template <int MT>
-static __device__ __forceinline__ void e8_epilogue_direct(const ConvKP& p, f32x4 (&acc)[MT][4], int m0w, int n0w, int l15,
-                                                          int lq) {
+// NPAIR = fragment pairs per wave (2 = the 64-channel wave tile of the main GEMM, 1 = the 32-channel one of the fused
+// pointwise layer); KEEP: the rounded f16 rows are also returned (keep[i][pr]) for that layer's LDS image; mrows = rows
+// of this wave's sub-tile that exist (the fused layer's last row group of a BM < 256 tile is partly empty).
+// pre_sc / pre_bi: this lane's 8 scale / bias values already in registers (NF == 2 only): the fused layer's epilogue then
+// issues no load at all -- a load here would queue behind the first epilogue's stores (vector memory returns in order).
+template <int MT, int NF = 4, bool KEEP = false>
+static __device__ __forceinline__ void e8_epilogue_direct(const ConvKP& p, f32x4 (&acc)[MT][NF], int m0w, int n0w, int l15,
+                                                          int lq, f16x8 (*keep)[NF / 2] = nullptr, int mrows = MT * 16,
+                                                          const float* pre_sc = nullptr, const float* pre_bi = nullptr) {
   // pixel decomposition once per m-fragment (shared by both fragment pairs)
   unsigned pb[MT], ppix[MT];
 #pragma unroll
@@ -63,11 +69,17 @@ static __device__ __forceinline__ void e8_epilogue_direct(const ConvKP& p, f32x4
     ppix[i] = (unsigned)m - pb[i] * (unsigned)p.HoWo;
   }
 #pragma unroll
-  for (int pr = 0; pr < 2; ++pr) {
+  for (int pr = 0; pr < NF / 2; ++pr) {
     const int n = n0w + (2 * pr + (lq & 1)) * 16 + (lq >> 1) * 8;  // this lane's 8 channels
     const bool nok = n < p.Cout;
     float sc[8], bi[8];
-    {
+    if (pre_sc) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sc[e] = pre_sc[e];
+        bi[e] = pre_bi[e];
+      }
+    } else {
       const f32x4 s0 = *(const f32x4*)(p.scale + n), s1 = *(const f32x4*)(p.scale + n + 4);
       const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
 #pragma unroll
@@ -99,7 +111,7 @@ static __device__ __forceinline__ void e8_epilogue_direct(const ConvKP& p, f32x4
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int m = m0w + i * 16 + l15;
-      const bool ok = nok && m < p.M;
+      const bool ok = nok && m < p.M && i * 16 + l15 < mrows;
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -134,6 +146,12 @@ static __device__ __forceinline__ void e8_epilogue_direct(const ConvKP& p, f32x4
           *(f16x8*)((f16*)p.out + ooff) = h;
         }
       }
+      if (KEEP) {
+        f16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (f16)v[e];
+        keep[i][pr] = h;
+      }
     }
   }
 }
@@ -143,7 +161,9 @@ static __device__ __forceinline__ void e8_epilogue_direct(const ConvKP& p, f32x4
 // BUF = 1: loaders are buffer_load_dwordx4 ... lds (resource in SGPRs, per-lane byte offset cached per filter tap,
 // K position in the scalar offset: no per-DMA address arithmetic, padding = out-of-range offset -> zeros);
 // BUF = 0: global_load_lds_dwordx4 with 64-bit per-lane addresses and the zero page (kept for A/B timing).
-template <int KS, int MF1, int DBG = 0, int BUF = 1>
+// PW: the pointwise (1x1) layer that consumes this tile's 256 output channels runs in the epilogue (see the end of the
+// kernel); the launch then writes both tensors and the 1x1 layer has no launch of its own.
+template <int KS, int MF1, int DBG = 0, int BUF = 1, bool PW = false>
 __global__ __launch_bounds__(512, 2) void od_conv_8ph(ConvKP p) {
   constexpr int MF0 = 4, MT = MF0 + MF1, WROWS = MT * 16, BM = 2 * WROWS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -290,6 +310,18 @@ __global__ __launch_bounds__(512, 2) void od_conv_8ph(ConvKP p) {
     }
   };
 
+  // PW: the second layer's weights (64 KiB: 4 k-slabs of [128 output channels][64 k], the ring's row format) stream into
+  // the K-tile buffer the LAST tile does not use, two DMAs per phase of that tile, so they have landed when the main loop ends
+  const int w2buf = ((nk - 1) & 1) ^ 1;
+  const __amdgpu_buffer_rsrc_t rs_w2 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(PW ? p.w2 : p.w), 0, (int)(PW ? p.w2_bytes : p.w_bytes), 0x00020000);
+  auto stage_w2 = [&](int ks) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      blds16(rs_w2, (unsigned)(((h * 64 + rr) * p.K2stride + lc * 8) * 2), ks * (E_BK * 2),
+             piece + w2buf * E_BUF + ks * E_REGION + h * 8192);
+  };
+
   f32x4 acc[MT][4];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -357,6 +389,9 @@ __global__ __launch_bounds__(512, 2) void od_conv_8ph(ConvKP p) {
     if (t + 1 < nk) {
       stage_b(1, t + 1, (t & 1) ^ 1);
       wait_vmcnt<8>();  // B-hi of tile t (read in the next phase) has landed
+    } else if (PW) {
+      stage_w2(0);
+      wait_vmcnt<2>();  // everything of tile t has landed, the two W2 pieces stay in flight
     } else {
       wait_vmcnt<0>();
     }
@@ -372,6 +407,8 @@ __global__ __launch_bounds__(512, 2) void od_conv_8ph(ConvKP p) {
     if (t + 1 < nk) {
       stage_a(1, walk_hi, (t & 1) ^ 1);
       wait_vmcnt<8>();  // A-hi of tile t
+    } else if (PW) {
+      stage_w2(1);  // (tile t landed in L0)
     } else {
       wait_vmcnt<0>();
     }
@@ -385,6 +422,7 @@ __global__ __launch_bounds__(512, 2) void od_conv_8ph(ConvKP p) {
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) ldf(xa[f][kh], cur + E_AHI + ((fa + f * 2048) ^ (kh * 64)));
     if (t + 2 < nk) stage_a(0, walk_lo, t & 1);
+    if (PW && t + 1 == nk) stage_w2(2);
     E8_STAMP(9);
   };
   auto L3 = [&](int t) {
@@ -392,6 +430,8 @@ __global__ __launch_bounds__(512, 2) void od_conv_8ph(ConvKP p) {
     if (t + 2 < nk) {
       stage_b(0, t + 2, t & 1);
       wait_vmcnt<8>();  // A-lo and B-lo of tile t+1
+    } else if (PW && t + 1 == nk) {
+      stage_w2(3);  // (nothing of the main loop is in flight any more; the barrier after the loop waits for W2)
     } else {
       wait_vmcnt<0>();
     }
@@ -470,7 +510,87 @@ __global__ __launch_bounds__(512, 2) void od_conv_8ph(ConvKP p) {
   __syncthreads();
   E8_CSTAMP(2);
 
-  if (p.splitk > 1) {
+  if (PW) {
+    // ---- fused pointwise layer: t = act2(scale2 * (y . W2) + bias2) for this tile's BM pixels, y = the f16 rows the
+    // epilogue below stores (all 256 channels of a pixel are in this workgroup: Cout == 256, one n tile).
+    // LDS: the K-tile buffer the last tile did not use = W2 as 4 k-slabs of [128 out channels][64 k] (128-B rows, the
+    // ring's swizzle; streamed in during the last K tile, see stage_w2), the other buffer = the y rows of ONE wave row
+    // (WROWS pixels x 4 channel slabs of 64), so the second GEMM runs in two passes.
+    const int rg = wave >> 2, cg = wave & 3;  // second GEMM: wave = 64 pixel rows x 32 output channels
+    float sc2[8], bi2[8];                      // its scale / bias, loaded BEFORE the first epilogue's stores are queued
+    {
+      const int n2 = cg * 32 + (lq & 1) * 16 + (lq >> 1) * 8;
+      const f32x4 s0 = *(const f32x4*)(p.scale2 + n2), s1 = *(const f32x4*)(p.scale2 + n2 + 4);
+      const f32x4 b0 = *(const f32x4*)(p.bias2 + n2), b1 = *(const f32x4*)(p.bias2 + n2 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc2[e] = s0[e];
+        sc2[4 + e] = s1[e];
+        bi2[e] = b0[e];
+        bi2[4 + e] = b1[e];
+      }
+    }
+    f16x8 ykeep[MT][2];
+    od_mfma_results_ready();
+    e8_epilogue_direct<MT, 4, true>(p, acc, m0 + wr * WROWS, n0 + wc * 64, l15, lq, ykeep);
+    ConvKP p2 = p;
+    p2.scale = p.scale2;
+    p2.bias = p.bias2;
+    p2.act = p.act2;
+    p2.alpha = p.alpha2;
+    p2.res_mode = OD_RES_NONE;
+    p2.out = (void*)p.out2;
+    p2.out_f32 = 0;
+    p2.Cout = p.Cout2;
+    p2.obs = (long long)p.HoWo * p.Cout2;
+    p2.ops = p.Cout2;
+    char* const ybuf = smem + (w2buf ^ 1) * E_BUF;
+    const char* const wbuf = smem + w2buf * E_BUF;
+    const int fy = (rg * 64 + l15) * 128 + ((lq ^ (l15 & 7)) * 16);
+    const int fw = (cg * 32 + l15) * 128 + ((lq ^ (l15 & 7)) * 16);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (wr == half) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const int row = i * 16 + l15;
+            const int chunk = (2 * pr + (lq & 1)) * 2 + (lq >> 1);
+            *(f16x8*)(ybuf + wc * E_REGION + row * 128 + ((chunk ^ (row & 7)) * 16)) = ykeep[i][pr];
+          }
+      }
+      // (W2 landed before the __syncthreads that closed the main loop.)  The epilogue's stores keep draining behind the
+      // second GEMM: a __syncthreads here would wait for them -> raw barrier
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      f32x4 acc2[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) acc2[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+          f16x8 wf[2], yf[4];
+#pragma unroll
+          for (int f = 0; f < 2; ++f) wf[f] = *(const f16x8*)(wbuf + ks * E_REGION + ((fw + f * 2048) ^ (kh * 64)));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) yf[i] = *(const f16x8*)(ybuf + ks * E_REGION + ((fy + i * 2048) ^ (kh * 64)));
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) acc2[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[f], yf[i], acc2[i][f], 0, 0, 0);
+        }
+      od_mfma_results_ready();
+      e8_epilogue_direct<4, 2>(p2, acc2, m0 + half * WROWS + rg * 64, cg * 32, l15, lq, nullptr, WROWS - rg * 64, sc2, bi2);
+      if (half == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave has read the first wave row's y image
+      }
+    }
+  } else if (p.splitk > 1) {
     conv_epilogue<E_BN, 2, 4, MT, 4, 512>(p, smem, acc, m0, n0, tid, wr, wc, l15, lq);  // f32 partial slabs
   } else {
     od_mfma_results_ready();
@@ -491,11 +611,17 @@ struct E8Entry {
   const void* k3;
   const char* name1;
   const char* name3;
+  const void* k1pw;  // + the consuming pointwise layer in the epilogue
+  const void* k3pw;
+  const char* name1pw;
+  const char* name3pw;
 };
 #define OD_E8(MF1)                                                                                        \
   {                                                                                                       \
     32 * (4 + MF1), (const void*)&od_conv_8ph<1, MF1>, (const void*)&od_conv_8ph<3, MF1>,                 \
-        "od_conv_8ph<1, " #MF1 ", 0, 1>", "od_conv_8ph<3, " #MF1 ", 0, 1>"                                          \
+        "od_conv_8ph<1, " #MF1 ", 0, 1, false>", "od_conv_8ph<3, " #MF1 ", 0, 1, false>",                             \
+        (const void*)&od_conv_8ph<1, MF1, 0, 1, true>, (const void*)&od_conv_8ph<3, MF1, 0, 1, true>,     \
+        "od_conv_8ph<1, " #MF1 ", 0, 1, true>", "od_conv_8ph<3, " #MF1 ", 0, 1, true>"                    \
   }
 const E8Entry g_e8[] = {OD_E8(4), OD_E8(3), OD_E8(2), OD_E8(1)};  // BM = 256, 224, 192, 160
 const void* const g_e8_dbg[][2] = {{(const void*)&od_conv_8ph<3, 4, 1>, "od_conv_8ph<3, 4, dbg1>"},
@@ -516,9 +642,10 @@ bool od_conv_8ph_select(int idx, const ConvKP& p, int ksize, ConvKernelInfo* inf
   if ((p.Cin & 63) != 0 || p.tconv) return false;
   if (p.x_bytes >= 0x7F000000u || p.w_bytes >= 0x7F000000u || p.x_bytes == 0) return false;  // E_OOB must stay out of range
   const E8Entry& e = g_e8[idx];
-  info->fn = ksize == 1 ? e.k1 : e.k3;
-  info->name = ksize == 1 ? e.name1 : e.name3;
-  if (idx == 0 && ksize == 3 && p.dbg) {
+  const bool pw = p.w2 != nullptr;  // the caller (od_conv2d_fwd) has checked od_conv_8ph_can_fuse_pointwise
+  info->fn = ksize == 1 ? (pw ? e.k1pw : e.k1) : (pw ? e.k3pw : e.k3);
+  info->name = ksize == 1 ? (pw ? e.name1pw : e.name1) : (pw ? e.name3pw : e.name3);
+  if (idx == 0 && ksize == 3 && p.dbg && !pw) {
     const int di = p.dbg == 1 ? 0 : p.dbg == 2 ? 1 : p.dbg == 8 ? 2 : p.dbg == 16 ? 3 : p.dbg == 32 ? 4 : p.dbg == 64 ? 5 : p.dbg == 128 ? 6 : -1;
     if (di >= 0) {
       info->fn = g_e8_dbg[di][0];

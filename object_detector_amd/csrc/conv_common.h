@@ -27,6 +27,16 @@ struct ConvKP {
   // training forward (od_conv_desc.bn_partials): per-channel partial sums of the STORED f16 outputs of this tile, row
   // mtile of [mtiles][2][Cout] f32 = (sum z, sum z^2): the BatchNorm statistics pass over z disappears
   float* stats;
+  // the pointwise layer that consumes this launch's output, run inside the epilogue (od_conv_desc.w2; 8-wave kernel only):
+  // out2[m][0..Cout2) = act2(scale2 * (out[m][0..Cout) . w2) + bias2), f16 dense NHWC
+  const f16* w2;
+  const float* scale2;
+  const float* bias2;
+  f16* out2;
+  int Cout2, act2;
+  float alpha2;
+  unsigned w2_bytes;
+  int K2stride;
 };
 
 static __device__ __forceinline__ void glds16(const void* gptr, void* lptr) {

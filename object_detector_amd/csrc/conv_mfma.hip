@@ -18,6 +18,7 @@
 // Replaces the Conv2D + BatchNormalization + LeakyReLU/ELU (+ Add) layers executed inside
 // `ObjectDetector.predict` (reference voc_validate.py:27; docs/MODEL.md:5-21).
 #include <stdlib.h>
+#include <string.h>
 
 #include "conv_common.h"
 
@@ -546,8 +547,41 @@ extern "C" int od_conv_weight_dims(int cout, int cin, int ksize, int* cout_pad, 
   return OD_OK;
 }
 
+static int od_conv2d_fwd_main(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, const char** kernel_name, bool dry_run,
+                              int* mtiles_out, bool* fused_out);
+
+// od_conv_desc.w2 (the pointwise layer that consumes this launch's output): inside the 8-wave kernel's epilogue when the
+// selected kernel can do it, otherwise as a second launch right behind the first -- the caller's plan is the same either way
 static int od_conv2d_fwd_impl2(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, const char** kernel_name, bool dry_run,
-                               int* mtiles_out);
+                               int* mtiles_out) {
+  bool fused = false;
+  const int rc = od_conv2d_fwd_main(ctx, d, stream, kernel_name, dry_run, mtiles_out, &fused);
+  if (rc != OD_OK || !d->w2 || fused || dry_run) return rc;
+  const int pad = d->ksize / 2;
+  od_conv_desc q;
+  memset(&q, 0, sizeof(q));
+  q.x = d->out;
+  q.w = d->w2;
+  q.scale = d->scale2;
+  q.bias = d->bias2;
+  q.out = d->out2;
+  q.B = d->B;
+  q.H = (d->H + 2 * pad - d->ksize) / d->stride + 1;
+  q.W = (d->W + 2 * pad - d->ksize) / d->stride + 1;
+  q.Cin = d->Cout;
+  q.Cout = d->Cout2;
+  q.ksize = 1;
+  q.stride = 1;
+  q.act = d->act2;
+  q.alpha = d->alpha2;
+  q.res_mode = OD_RES_NONE;
+  q.out_dtype = OD_DT_F16;
+  q.tile_cfg = d->tile_cfg < 0 ? d->tile_cfg : -1;
+  q.splitk = d->splitk;
+  q.splitk_workspace = d->splitk_workspace;  // same stream: the first launch's finish kernel is done with it
+  q.splitk_workspace_bytes = d->splitk_workspace_bytes;
+  return od_conv2d_fwd_main(ctx, &q, stream, nullptr, false, nullptr, nullptr);
+}
 
 int od_conv2d_fwd_impl(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, const char** kernel_name,
                        bool dry_run) {
@@ -558,8 +592,8 @@ static int od_conv2d_fwd_rows_impl(od_ctx* ctx, const od_conv_desc* d, int* rows
   return od_conv2d_fwd_impl2(ctx, d, nullptr, nullptr, true, rows);
 }
 
-static int od_conv2d_fwd_impl2(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, const char** kernel_name, bool dry_run,
-                               int* mtiles_out) {
+static int od_conv2d_fwd_main(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, const char** kernel_name, bool dry_run,
+                              int* mtiles_out, bool* fused_out) {
   OD_REQUIRE(ctx && d, "od_conv2d_fwd: null ctx/desc");
   OD_REQUIRE(d->x && d->w && d->scale && d->bias && d->out, "od_conv2d_fwd: null tensor");
   OD_REQUIRE(d->ksize == 1 || d->ksize == 3, "od_conv2d_fwd: ksize %d unsupported", d->ksize);
@@ -591,6 +625,16 @@ static int od_conv2d_fwd_impl2(od_ctx* ctx, const od_conv_desc* d, hipStream_t s
     OD_REQUIRE(!tconv && d->out_dtype == OD_DT_F16 && d->act == OD_ACT_LINEAR && d->res_mode == OD_RES_NONE,
                "od_conv2d_fwd: bn_partials needs the raw convolution (f16 output, no activation, no residual, no transposed "
                "gather; scale / bias are NOT applied)");
+  if (d->w2) {
+    OD_REQUIRE(d->scale2 && d->bias2 && d->out2 && d->Cout2 > 0 && d->Cout2 % 8 == 0,
+               "od_conv2d_fwd: w2 needs scale2, bias2, out2 and Cout2 (a multiple of 8)");
+    OD_REQUIRE(d->act2 >= OD_ACT_LINEAR && d->act2 <= OD_ACT_ELU, "od_conv2d_fwd: bad act2");
+    OD_REQUIRE(d->act2 != OD_ACT_LEAKY || (d->alpha2 >= 0.f && d->alpha2 <= 1.f), "od_conv2d_fwd: leaky slope (alpha2) must be in [0, 1]");
+    OD_REQUIRE(d->out_dtype == OD_DT_F16 && !tconv && !want_stats && d->Cout % 8 == 0 &&
+                   (d->out_batch_stride == 0 || d->out_batch_stride == (long long)Ho * Wo * d->Cout) &&
+                   (d->out_pix_stride == 0 || d->out_pix_stride == d->Cout),
+               "od_conv2d_fwd: w2 (the consuming pointwise layer) needs a dense f16 output of the first layer");
+  }
   int cfg = d->tile_cfg;
   if (cfg < 0)  // (the 8-wave kernel has its own epilogue without the statistics path: not offered when they are asked for)
     cfg = pick_cfg(ctx, M, d->Cin, d->Cout, d->ksize,
@@ -641,6 +685,15 @@ static int od_conv2d_fwd_impl2(od_ctx* ctx, const od_conv_desc* d, hipStream_t s
   p.res_mode = d->res_mode;
   p.out_f32 = d->out_dtype == OD_DT_F32;
   p.stats = d->bn_partials;
+  p.w2 = nullptr;  // set below when the selected kernel runs the consuming pointwise layer in its epilogue
+  p.scale2 = d->scale2;
+  p.bias2 = d->bias2;
+  p.out2 = (f16*)d->out2;
+  p.Cout2 = d->Cout2;
+  p.act2 = d->act2;
+  p.alpha2 = d->alpha2;
+  p.K2stride = od_round_up(d->Cout, 64);
+  p.w2_bytes = (unsigned)((long long)od_round_up(d->Cout2 > 0 ? d->Cout2 : 1, 256) * p.K2stride * 2);
   p.x_bytes = (unsigned)((long long)d->B * d->H * d->W * d->Cin * 2);
   p.w_bytes = (unsigned)((long long)od_round_up(d->Cout, 256) * p.Kstride * 2);
   p.obs = d->out_batch_stride ? d->out_batch_stride : (long long)p.HoWo * d->Cout;
@@ -755,6 +808,21 @@ static int od_conv2d_fwd_impl2(od_ctx* ctx, const od_conv_desc* d, hipStream_t s
       p.splitk = od_ceil_div(nk, p.steps_per_split);
     }
   }
+  // the consuming pointwise layer inside the epilogue: 8-wave kernel, one n tile holding all 256 channels of a pixel, 128
+  // output channels (W2 = 64 KiB of LDS), no split-K slabs
+  if (d->w2 && use_e8 && p.splitk == 1 && d->Cout == 256 && d->Cout2 == 128) {
+    static int allow = -1;
+    if (allow < 0) {
+      const char* e = getenv("OD_FUSE_POINTWISE");  // 0 = always two launches (A/B timing)
+      allow = e ? atoi(e) : 1;
+    }
+    if (allow) {
+      p.w2 = (const f16*)d->w2;
+      size_t lds = 0;
+      if (!od_conv_8ph_select(cfg - cfg_e8, p, d->ksize, &e8, &lds)) return OD_ERR_INVALID;
+    }
+  }
+  if (fused_out) *fused_out = p.w2 != nullptr;
   // weights/scale/bias are padded to a multiple of 256 output channels, so any BN <= 256 tile stays in bounds.
 
   // kernel variant: 1x1 / 3x3-uniform-tap / 3x3-generic (odd channel counts fall back to a config that has one)

@@ -149,7 +149,10 @@ class Net:
         return t
 
     def _conv(self, name, x, h, w, cin, cout, k, stride, act, res=None, res_mode=_lib.OD_RES_NONE, out=None,
-              out_f32=False, obs=0, ops=0):
+              out_f32=False, obs=0, ops=0, then=None):
+        """then = (name2, cout2, act2): the pointwise layer that consumes this layer's output rides in the same op
+        (od_conv_desc.w2: inside the 8-wave kernel's epilogue, or as a second launch of the library's choosing);
+        returns (out, ho, wo, out2) then."""
         wt, sc, bi = self._dev[name]
         ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
         if out is None:
@@ -169,6 +172,14 @@ class Net:
             pre, star, suf = pat.partition("*")
             if star and name.startswith(pre) and name.endswith(suf):
                 d.tile_cfg = cfg
+        out2 = None
+        if then is not None:
+            name2, cout2, act2 = then
+            w2, sc2, bi2 = self._dev[name2]
+            out2 = self._buf(ho, wo, cout2)
+            d.w2, d.scale2, d.bias2, d.out2 = w2.data_ptr(), sc2.data_ptr(), bi2.data_ptr(), out2.data_ptr()
+            d.Cout2 = cout2
+            d.act2, d.alpha2 = _lib.ACT_ENUM[act2[0] if act2 else None], float(act2[1]) if act2 else 0.0
         m = self.B * ho * wo
         if self.splitk and m * cout <= (1 << 22):  # candidates only; the library decides per layer
             self._splitk_elems = max(self._splitk_elems, m * cout)
@@ -186,6 +197,12 @@ class Net:
                                  # the op's tensors, for per-layer parity checks (tests/test_gpu_fullsize.py)
                                  kind="conv", x=x, res=res, res_mode=res_mode, out=None if isinstance(out, int) else out,
                                  stride=stride, ksize=k, act=act, out_f32=out_f32))
+        if then is not None:
+            inf = self.op_info[-1]
+            inf["flops"] += 2.0 * m * cout2 * cout
+            inf["bytes"] += float(m * cout2 * 2 + cout2 * cout * 2)  # the 1x1's input never comes back from HBM
+            inf["then"] = dict(name=name2, out=out2, act=act2)
+            return out, ho, wo, out2
         return out, ho, wo
 
     def _bneck(self, name, x, h, w, ch, act):
@@ -252,18 +269,31 @@ class Net:
         h, w, cin = H, Wd, 32
         taps = []
         for si, (n, ch) in enumerate(W.STAGES, start=1):
+            fused_block = (self.fuse_blocks and os.environ.get(f"OD_FUSE_BNECK{ch}", "1") != "0"
+                           and self.lib.od_bottleneck_supported(h // 2, w // 2, ch))
+            # 256-channel stage: a block's 1x1 (256 -> 128) rides in the launch that PRODUCES its input (the stride-2 conv
+            # or the previous block's 3x3 -- all 256 channels of a pixel are in one workgroup of the 8-wave kernel)
+            ride = self.fuse_blocks and ch == 256 and not fused_block and os.environ.get("OD_FUSE_POINTWISE", "1") != "0"
+            t = None
             if si == 1 and fuse_stem:
                 h, w = h // 2, w // 2
+            elif ride:
+                x, h, w, t = self._conv(f"b.down{si}", x, h, w, cin, ch, 3, 2, bact, then=(f"b.s{si}.0.a", ch // 2, bact))
             else:
                 x, h, w = self._conv(f"b.down{si}", x, h, w, cin, ch, 3, 2, bact)
             for r in range(n):
-                if (self.fuse_blocks and os.environ.get(f"OD_FUSE_BNECK{ch}", "1") != "0"
-                        and self.lib.od_bottleneck_supported(h, w, ch)):
+                if fused_block:
                     x = self._bneck(f"b.s{si}.{r}", x, h, w, ch, bact)
                     continue
-                t, _, _ = self._conv(f"b.s{si}.{r}.a", x, h, w, ch, ch // 2, 1, 1, bact)
-                x, _, _ = self._conv(f"b.s{si}.{r}.b", t, h, w, ch // 2, ch, 3, 1, bact, res=x,
-                                     res_mode=_lib.OD_RES_SAME)
+                if t is None:
+                    t, _, _ = self._conv(f"b.s{si}.{r}.a", x, h, w, ch, ch // 2, 1, 1, bact)
+                if ride and r + 1 < n:
+                    x, _, _, t = self._conv(f"b.s{si}.{r}.b", t, h, w, ch // 2, ch, 3, 1, bact, res=x,
+                                            res_mode=_lib.OD_RES_SAME, then=(f"b.s{si}.{r + 1}.a", ch // 2, bact))
+                else:
+                    x, _, _ = self._conv(f"b.s{si}.{r}.b", t, h, w, ch // 2, ch, 3, 1, bact, res=x,
+                                         res_mode=_lib.OD_RES_SAME)
+                    t = None
             cin = ch
             taps.append((x, h, w, ch))
         (c3, h3, w3, ch3), (c4, h4, w4, ch4), (c5, h5, w5, ch5) = taps[2], taps[3], taps[4]

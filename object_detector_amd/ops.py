@@ -19,8 +19,10 @@ def _ctx(t: torch.Tensor) -> Context:
 
 def conv2d(x: torch.Tensor, w_ohwi: np.ndarray, scale: np.ndarray, bias: np.ndarray, stride=1, act=None, alpha=0.0,
            res: torch.Tensor | None = None, res_mode="none", out_f32=False, tile_cfg=-1, out=None,
-           out_batch_stride=0, out_pix_stride=0, splitk=1, splitk_ws=None):
-    """x f16 [B,H,W,Cin] (device) ; w [Cout,k,k,Cin] host array -> out f16/f32 [B,Ho,Wo,Cout]."""
+           out_batch_stride=0, out_pix_stride=0, splitk=1, splitk_ws=None, next_pointwise=None):
+    """x f16 [B,H,W,Cin] (device) ; w [Cout,k,k,Cin] host array -> out f16/f32 [B,Ho,Wo,Cout].
+    next_pointwise = (w2 [Cout2,1,1,Cout], scale2, bias2, act2, alpha2): the 1x1 layer that consumes `out`
+    (od_conv_desc.w2) -> returns (out, out2)."""
     ctx = _ctx(x)
     assert x.dtype == torch.float16 and x.is_contiguous()
     B, H, Wd, Cin = x.shape
@@ -46,9 +48,22 @@ def conv2d(x: torch.Tensor, w_ohwi: np.ndarray, scale: np.ndarray, bias: np.ndar
         if splitk_ws is None:
             splitk_ws = torch.empty(32 * B * Ho * Wo * Cout, dtype=torch.float32, device=x.device)
         d.splitk, d.splitk_workspace, d.splitk_workspace_bytes = splitk, splitk_ws.data_ptr(), splitk_ws.numel() * 4
+    out2 = None
+    if next_pointwise is not None:
+        w2, scale2, bias2, act2, alpha2 = next_pointwise
+        assert w2.shape[1:] == (1, 1, Cout)
+        w2p = torch.from_numpy(pack_conv_weight(w2)).to(x.device)
+        sc2 = torch.from_numpy(pad_vec(np.asarray(scale2, np.float32), w2p.shape[0])).to(x.device)
+        bi2 = torch.from_numpy(pad_vec(np.asarray(bias2, np.float32), w2p.shape[0])).to(x.device)
+        out2 = torch.empty((B, Ho, Wo, w2.shape[0]), dtype=torch.float16, device=x.device)
+        d.w2, d.scale2, d.bias2, d.out2 = w2p.data_ptr(), sc2.data_ptr(), bi2.data_ptr(), out2.data_ptr()
+        d.Cout2, d.act2, d.alpha2 = w2.shape[0], _lib.ACT_ENUM[act2], float(alpha2)
     _lib.check(ctx.lib.od_conv2d_fwd(ctx.handle, C.byref(d), _stream_ptr()), "od_conv2d_fwd")
     if splitk != 1:
         out._splitk_ws = splitk_ws  # keep the workspace alive / inspectable
+    if next_pointwise is not None:
+        torch.cuda.current_stream().synchronize()  # the packed second-layer weights above are temporaries
+        return out, out2
     return out
 
 

@@ -108,6 +108,61 @@ def test_conv_matches_oracle(cuda, case):
     assert (err <= tol).all(), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
 
 
+PW_CASES = []
+for _c in range(NE8, NE8 + NE8N):  # every BM of the 8-wave kernel: the second layer runs in the epilogue
+    PW_CASES += [(2, 20, 20, 128, 256, 3, 1, "leaky", "same", "leaky", _c),   # stage-3 block: 3x3 + residual, then the next 1x1
+                 (1, 40, 40, 128, 256, 3, 2, "leaky", "none", "leaky", _c),   # the stride-2 conv that opens the stage
+                 (3, 9, 7, 192, 256, 3, 1, "elu", "same", "elu", _c),         # ragged last tile (189 pixels), ELU on both
+                 (2, 10, 10, 512, 256, 1, 1, "leaky", "up2", None, _c)]       # 1x1 first layer, upsampled residual, linear second
+PW_CASES += [(2, 20, 20, 128, 256, 3, 1, "leaky", "same", "leaky", -1),        # library's choice: fused or two launches
+             (2, 20, 20, 128, 256, 3, 1, "leaky", "same", "leaky", 13),       # table kernel: always two launches
+             (2, 12, 12, 64, 128, 3, 1, "leaky", "same", "leaky", NE8),       # Cout != 256: two launches
+             (8, 40, 40, 128, 256, 3, 1, "leaky", "same", "leaky", -2)]       # throughput-mode choice at a multi-tile size
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=str)
+def test_conv_with_consuming_pointwise_layer(cuda, case):
+    """od_conv_desc.w2: the 1x1 layer that consumes the launch's output, inside the 8-wave kernel's epilogue (or as a
+    second launch where the selected kernel cannot).  `out` must be BIT-identical to the launch without w2; `out2` is
+    checked against the f64 oracle applied to the DEVICE's f16 `out` (same rounding points as two separate layers):
+    1 f16 ulp + 1e-3 of the output scale."""
+    from object_detector_amd import ops
+    B, H, W, Cin, Cout, k, stride, act, resm, act2, cfg = case
+    Cout2 = Cout // 2
+    rng = np.random.default_rng(hash(case) & 0xFFFF)
+    x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float16)
+    w = (rng.normal(0, 1, (Cout, k, k, Cin)) * np.sqrt(2.0 / (k * k * Cin))).astype(np.float16)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    bias = rng.normal(0, 0.1, Cout).astype(np.float32)
+    w2 = (rng.normal(0, 1, (Cout2, 1, 1, Cout)) * np.sqrt(2.0 / Cout)).astype(np.float16)
+    scale2 = rng.uniform(0.5, 1.5, Cout2).astype(np.float32)
+    bias2 = rng.normal(0, 0.1, Cout2).astype(np.float32)
+    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    res = None
+    if resm == "same":
+        res = rng.normal(0, 1, (B, Ho, Wo, Cout)).astype(np.float16)
+    elif resm == "up2":
+        res = rng.normal(0, 1, (B, Ho // 2, Wo // 2, Cout)).astype(np.float16)
+    alpha = 0.1 if act == "leaky" else 1.0
+    alpha2 = 0.1 if act2 == "leaky" else 1.0
+    xt = torch.from_numpy(x).to(cuda)
+    rt = torch.from_numpy(res).to(cuda) if res is not None else None
+    plain = ops.conv2d(xt, w.astype(np.float32), scale, bias, stride=stride, act=act, alpha=alpha, res=rt, res_mode=resm,
+                       tile_cfg=cfg)
+    out, out2 = ops.conv2d(xt, w.astype(np.float32), scale, bias, stride=stride, act=act, alpha=alpha, res=rt,
+                           res_mode=resm, tile_cfg=cfg,
+                           next_pointwise=(w2.astype(np.float32), scale2, bias2, act2, alpha2))
+    torch.cuda.synchronize()
+    assert torch.equal(out, plain), "the first layer's output must not depend on the second layer being attached"
+    y = out.cpu().numpy().astype(np.float32)
+    ref2 = _ref(y, w2.astype(np.float32), scale2, bias2, 1, act2, alpha2)
+    got2 = out2.cpu().numpy().astype(np.float64)
+    assert got2.shape == ref2.shape == (B, Ho, Wo, Cout2)
+    err = np.abs(got2 - ref2)
+    tol = 1e-3 * max(1.0, np.abs(ref2).max()) + 2.0 ** -10 * np.abs(ref2)
+    assert (err <= tol).all(), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
+
+
 @pytest.mark.parametrize("case", [
     # B, H, W, Cin, Cout, k, stride, act, res, cfg, splitk
     (1, 10, 10, 512, 1024, 3, 1, "leaky", "same", 13, 0),   # batch-1 stage-5 shape, library-chosen split

@@ -126,6 +126,19 @@ def _check_layers_in_isolation(net, params, tag):
         assert mx <= 1.0, f"{tag} {name} ({kname}): {float(err.max()):.3e} off the oracle on identical inputs (rms {rms:.3f}, {mx:.2f} x tol)"
         assert frac <= 0.02, f"{tag} {name} ({kname}): {frac:.3%} of the outputs differ from the oracle on identical inputs"
         worst_frac = max(worst_frac, frac)
+        if inf.get("then"):  # the consuming 1x1 layer rode in the same op: its input is the op's own f16 output
+            nx = inf["then"]
+            r2 = run.conv(d, nx["name"], act=nx["act"])
+            A2 = mag.conv(np.abs(d), nx["name"])
+            d2 = nx["out"].cpu().numpy().astype(np.float32)
+            r2_16 = r2.astype(np.float16).astype(np.float32)
+            err2 = np.abs(d2 - r2_16)
+            mx2 = float((err2 / (_f16_ulp(r2_16) + np.float32(2.0 ** -20) * A2)).max())
+            frac2 = float(np.mean(d2 != r2_16))
+            rows.append((nx["name"], kname + " (second layer)", "f16", mx2, frac2))
+            assert mx2 <= 1.0, f"{tag} {nx['name']} (in the epilogue of {kname}): {float(err2.max()):.3e} off the oracle, {mx2:.2f} x tol"
+            assert frac2 <= 0.02, f"{tag} {nx['name']} (in the epilogue of {kname}): {frac2:.3%} of the outputs differ"
+            worst_frac = max(worst_frac, frac2)
     print(f"[{tag}] per-layer isolation: {len(rows)} ops, worst mismatch fraction {worst_frac:.2e}, "
           f"worst error / tolerance {max(r_[3] for r_ in rows):.2f}")
     for r_ in sorted(rows, key=lambda t: -t[4])[:5]:
@@ -159,6 +172,7 @@ def test_inference_at_baseline_config(cuda, B, S):
     print("kernels of the throughput-mode plan:", kernels)
     if S == 320:
         assert any(k.startswith("od_conv_8ph") for k in kernels) and any("od_stem" in k for k in kernels)
+        assert any(k.startswith("od_conv_8ph") and k.endswith("true>") for k in kernels), "stage 3: 1x1 in the producer's epilogue"
     for o in outs[1:]:  # the three pipelines share the weights and must agree bit for bit
         assert np.array_equal(o["pred"], outs[0]["pred"]) and np.array_equal(o["keep"], outs[0]["keep"])
     o = outs[0]
