@@ -418,7 +418,15 @@ def main():
                          "algorithmic_gflop_per_launch": round(g["flops"] / g["n"] / 1e9, 3),
                          "network_ms_per_batch": round(net_ms, 4),
                          "network_tflops": round(sum(i["flops"] for i in info) / (net_ms * 1e-3) / 1e12, 2),
-                         "traffic": traffic},
+                         "traffic": traffic,
+                         # the other instantiations of the same 8-wave kernel (since round 2 the stage-3 launches also run
+                         # the consuming 1x1 layer in their epilogue and are a kernel symbol of their own)
+                         "same_kernel_other_instantiations": [
+                             {"kernel": k, "launches_per_step": v["n"], "avg_launch_us": round(v["ms"] / v["n"] * 1e3, 2),
+                              "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                              "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4)}
+                             for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])
+                             if k != dom and k.split("<")[0] == dom.split("<")[0]][:3]},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(size, a.cpu_seconds)
