@@ -291,3 +291,6 @@ bool od_conv_pw_select(const ConvKP& p, int num_cu, ConvKernelInfo* info, size_t
 int od_conv_8ph_num_cfgs();
 bool od_conv_8ph_select(int idx, const ConvKP& p, int ksize, ConvKernelInfo* info, size_t* lds_bytes);
 bool od_conv_win_select(int idx, const ConvKP& p, ConvKernelInfo* info, size_t* lds_bytes);
+// conv_tconv.hip: streaming backward-data kernel of the first stride-2 convolution (dZ 64 channels -> dX 32 channels)
+bool od_tconv_small_supported(const od_conv_desc* d);
+int od_tconv_small_launch(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, const char** kernel_name, bool dry_run);
