@@ -7,7 +7,9 @@
 //
 // Replaces the preprocess (x/255 folded into `scale`) + first Conv2D/BN/LeakyReLU of `ObjectDetector.predict`
 // (reference voc_validate.py:27).
-#include "common.h"
+#include <stdlib.h>
+
+#include "conv_common.h"
 
 namespace {
 
@@ -138,10 +140,152 @@ __global__ __launch_bounds__(256) void od_conv_first_wgrad_finish(const float* _
   for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
   if (lane == 0) dw[i] += s * in_scale;
 }
+
+// ---- streaming form (W % 32 == 0): no widened copy of the image, no generic kernel ------------------------------------
+// D[co][j] = sum_p dZ[p][co] * X[p][j], j = tap*3 + c (27 of 32 columns): per 32-pixel chunk of an image row ONE 2-KiB
+// contiguous piece of dZ (LDS-DMA, then the transposing LDS read forms the MFMA operand: channel l15 of pixels 8*lq .. +7)
+// and 16 byte loads per lane of the uint8 image (pixel 8*lq + e shifted by the lane's tap, channel c; the 3 x 34 x 3-byte
+// window of a chunk lives in L1), 4 v_mfma_f32_16x16x32_f16.  Every wave walks its own chunks (chunk = wave index + k *
+// total waves) with the next chunk's loads in flight, keeps the 32 x 32 f32 sums in 16 registers, the four waves of a
+// workgroup are added in order through LDS, one [32][32] slab per workgroup, od_conv_first_wgrad_finish2 adds the slabs in
+// a fixed order.  224 -> 60 us at 32 x 320^2 (the widening pass + the generic kernel at 14 % tile use + finish before).
+typedef __fp16 h4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+__global__ __launch_bounds__(256) void od_conv_first_wgrad_stream(const uint8_t* __restrict__ x, const f16* __restrict__ dz,
+                                                                  float* __restrict__ slabs, int H, int W,
+                                                                  int chunks_per_row, int nchunks) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * 2 * 2048];  // per wave: two 2-KiB dZ chunks; reused for the wave sums
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int tq = l15 >> 2, tp = l15 & 3;
+  char* const mybuf = lds + wave * 4096;
+  const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+
+  // this lane's two image columns j = fj*16 + l15 -> (dy, dx, c); j >= 27: zero column
+  int jdy[2], jdx[2], jc[2];
+  bool jok[2];
+#pragma unroll
+  for (int fj = 0; fj < 2; ++fj) {
+    const int j = fj * 16 + l15;
+    const int tap = j / 3;
+    jok[fj] = j < 27;
+    jc[fj] = j - tap * 3;
+    jdy[fj] = tap / 3 - 1;
+    jdx[fj] = tap % 3 - 1;
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  unsigned char xb[2][8];  // raw bytes of the chunk whose loads are in flight
+  auto issue = [&](int chunk, int buf) {
+    const int row = chunk / chunks_per_row, x0 = (chunk - row * chunks_per_row) * 32;
+    const int b = row / H, y = row - b * H;
+    const f16* src = dz + ((long long)row * W + x0) * 32;
+    glds16(src + lane * 8, mybuf + buf * 2048);
+    glds16(src + 512 + lane * 8, mybuf + buf * 2048 + 1024);
+#pragma unroll
+    for (int fj = 0; fj < 2; ++fj) {
+      const int py = y + jdy[fj];
+      const bool rowok = jok[fj] && (unsigned)py < (unsigned)H;
+      const uint8_t* rp = x + ((long long)(b * H + py) * W) * 3 + jc[fj];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int px = x0 + 8 * lq + e + jdx[fj];
+        unsigned char v = 0;
+        if (rowok && (unsigned)px < (unsigned)W) v = rp[px * 3];
+        xb[fj][e] = v;
+      }
+    }
+  };
+
+  int chunk = gw;
+  int buf = 0;
+  if (chunk < nchunks) issue(chunk, 0);
+  while (chunk < nchunks) {
+    // everything of `chunk` has landed (18 vector-memory operations per chunk; nothing younger is in flight yet)
+    wait_vmcnt<0>();
+    f16x8 bf[2];
+#pragma unroll
+    for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bf[fj][e] = (f16)(float)xb[fj][e];
+    f16x8 af[2];
+    const char* cb = mybuf + buf * 2048;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      h4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+          (__attribute__((address_space(3))) h4v*)(cb + (8 * lq + tq) * 64 + f * 32 + tp * 8));
+      h4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+          (__attribute__((address_space(3))) h4v*)(cb + (8 * lq + 4 + tq) * 64 + f * 32 + tp * 8));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        af[f][e] = (f16)lo[e];
+        af[f][4 + e] = (f16)hi[e];
+      }
+    }
+    const int next = chunk + nw;
+    if (next < nchunks) issue(next, buf ^ 1);  // (the transposed reads above are complete before their values are used below;
+                                               //  the DMA targets the OTHER buffer)
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int fj = 0; fj < 2; ++fj) acc[f][fj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bf[fj], acc[f][fj], 0, 0, 0);
+    chunk = next;
+    buf ^= 1;
+  }
+  // ---- the four waves' sums, added in wave order; acc[f][fj][e] = D[f*16 + lq*4 + e][fj*16 + l15]
+  wait_vmcnt<0>();
+  __syncthreads();
+  float* red = (float*)lds;  // [wave][32][32]
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[(wave * 32 + f * 16 + lq * 4 + e) * 32 + fj * 16 + l15] = acc[f][fj][e];
+  __syncthreads();
+  float* out = slabs + (long long)blockIdx.x * 1024;
+  for (int i = tid; i < 1024; i += 256) out[i] = ((red[i] + red[1024 + i]) + red[2048 + i]) + red[3072 + i];
+}
+
+// one wave per output element: lane l adds the slabs l, l+64, ... in ascending order, then a fixed butterfly over the lanes
+__global__ __launch_bounds__(256) void od_conv_first_wgrad_finish2(const float* __restrict__ slabs, int nslabs,
+                                                                   float* __restrict__ dw, float in_scale) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // output element co*27 + j
+  const int lane = threadIdx.x & 63;
+  if (i >= 32 * 27) return;
+  const int co = i / 27, j = i - co * 27;
+  float s = 0.f;
+  for (int sp = lane; sp < nslabs; sp += 64) s += slabs[(long long)sp * 1024 + co * 32 + j];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) dw[i] += s * in_scale;
+}
 }  // namespace
+
+static bool first_wgrad_use_stream(int B, int H, int W) {
+  static int stream_ok = -1;
+  if (stream_ok < 0) {
+    const char* e = getenv("OD_FIRST_WGRAD_STREAM");  // 0 = the widened-copy + generic-kernel path (A/B timing)
+    stream_ok = e ? atoi(e) : 1;
+  }
+  return stream_ok && W % 32 == 0 && (long long)B * H * W < (1LL << 31);
+}
+
+static int first_wgrad_stream_wgs(const od_ctx* ctx, int B, int H, int W) {
+  const long long nchunks = (long long)B * H * (W / 32);
+  long long wgs = 4LL * (ctx->num_cu > 0 ? ctx->num_cu : 256);
+  if (wgs * 4 > nchunks) wgs = (nchunks + 3) / 4;
+  return (int)wgs;
+}
 
 extern "C" size_t od_conv_first_bwd_weight_workspace_bytes(od_ctx* ctx, int B, int H, int W) {
   if (!ctx || B <= 0 || H <= 0 || W <= 0) return 0;
+  if (first_wgrad_use_stream(B, H, W)) return (size_t)first_wgrad_stream_wgs(ctx, B, H, W) * 1024 * sizeof(float);
   const size_t x8 = (size_t)B * H * W * 16;
   const int split = od_conv2d_bwd_weight_splits(ctx, B, H, W, 8, 32, 3, 1);
   return x8 + (size_t)split * 32 * 72 * sizeof(float);
@@ -157,6 +301,16 @@ extern "C" int od_conv_first_bwd_weight(od_ctx* ctx, const uint8_t* x, const voi
   }
   OD_REQUIRE(((uintptr_t)workspace & 15) == 0, "od_conv_first_bwd_weight: workspace must be 16-byte aligned");
   const long long npix = (long long)B * H * W;
+  if (first_wgrad_use_stream(B, H, W)) {
+    const int wgs = first_wgrad_stream_wgs(ctx, B, H, W);
+    hipLaunchKernelGGL(od_conv_first_wgrad_stream, dim3(wgs), dim3(256), 0, (hipStream_t)stream, x, (const f16*)dz,
+                       (float*)workspace, H, W, W / 32, (int)(npix / 32));
+    OD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(od_conv_first_wgrad_finish2, dim3(32 * 27 / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, wgs, dw, in_scale);
+    OD_CHECK_LAUNCH();
+    return OD_OK;
+  }
   f16* x8 = (f16*)workspace;
   float* slabs = (float*)((char*)workspace + (size_t)npix * 16);
   long long blocks = (npix + 255) / 256;

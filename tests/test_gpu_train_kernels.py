@@ -360,3 +360,40 @@ def test_first_downsample_backward_data_streaming_kernel(cuda, case):
     bad = (af - gf).abs() > tol
     assert not bool(bad.any()), f"{int(bad.sum())} elements differ, max {float((af - gf).abs().max())}"
     print(f"{case}: {float((a != g).float().mean()):.2e} of the elements differ in the last bit from the generic path")
+
+
+@pytest.mark.parametrize("case", [(2, 8, 32), (3, 20, 64), (2, 12, 48), (1, 5, 96), (8, 96, 96)], ids=str)
+def test_first_layer_weight_gradient(cuda, case):
+    """od_conv_first_bwd_weight: dW[co][tap*3 + c] += in_scale * sum over pixels of dz[p][co] * x_u8[p shifted by tap][c],
+    f32, on the streaming kernel (W % 32 == 0) and on the widened-copy path (W = 48) vs torch's conv2d weight gradient in
+    f64; it ACCUMULATES into dw; two runs are bit-identical (fixed summation order, no atomics)."""
+    import ctypes as C
+    from object_detector_amd import _lib
+    from object_detector_amd.net import Context
+    B, H, W = case
+    rng = np.random.default_rng(H * 100 + W)
+    x = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    dz = rng.normal(0, 1, (B, H, W, 32)).astype(np.float16)
+    xt = torch.tensor(x.astype(np.float64) / 255.0).permute(0, 3, 1, 2)
+    wt = torch.zeros((32, 3, 3, 3), dtype=torch.float64, requires_grad=True)
+    F.conv2d(xt, wt, padding=1).backward(torch.tensor(dz.astype(np.float64)).permute(0, 3, 1, 2))
+    ref = wt.grad.permute(0, 2, 3, 1).numpy().reshape(32, 27)  # [co][(dy*3 + dx)*3 + c]
+    ctx = Context.get(cuda)
+    lib, h = ctx.lib, ctx.handle
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    xd, dzd = torch.from_numpy(x).to(cuda), torch.from_numpy(dz).to(cuda)
+    nb = lib.od_conv_first_bwd_weight_workspace_bytes(h, B, H, W)
+    assert nb > 0
+    ws = torch.empty(nb, dtype=torch.uint8, device=cuda)
+    base = rng.normal(0, 1, (32, 27)).astype(np.float32)
+    outs = []
+    for _ in range(2):
+        dw = torch.from_numpy(base.copy()).to(cuda)
+        ws.fill_(0xFF)  # NaN patterns: every slab element that is read must have been written
+        _lib.check(lib.od_conv_first_bwd_weight(h, xd.data_ptr(), dzd.data_ptr(), dw.data_ptr(), B, H, W, 32, 1.0 / 255.0,
+                                                ws.data_ptr(), nb, s), "od_conv_first_bwd_weight")
+        torch.cuda.synchronize()
+        outs.append(dw.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    got = outs[0].astype(np.float64) - base
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
