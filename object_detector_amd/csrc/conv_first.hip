@@ -278,7 +278,7 @@ static bool first_wgrad_use_stream(int B, int H, int W) {
 
 static int first_wgrad_stream_wgs(const od_ctx* ctx, int B, int H, int W) {
   const long long nchunks = (long long)B * H * (W / 32);
-  long long wgs = 4LL * (ctx->num_cu > 0 ? ctx->num_cu : 256);
+  long long wgs = 6LL * (ctx->num_cu > 0 ? ctx->num_cu : 256);  // 6 waves per SIMD (64 VGPRs, 16 KiB LDS per workgroup): all resident
   if (wgs * 4 > nchunks) wgs = (nchunks + 3) / 4;
   return (int)wgs;
 }
