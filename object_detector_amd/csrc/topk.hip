@@ -119,8 +119,9 @@ __global__ __launch_bounds__(256) void od_topk_partition(const float* __restrict
                                                          TopkState* __restrict__ st, unsigned long long* __restrict__ keys,
                                                          unsigned* __restrict__ cand, int K, int chunk) {
   extern __shared__ __attribute__((aligned(16))) unsigned sm_u[];
-  unsigned* l_out = sm_u;           // [chunk] flat indices going straight to the output
-  unsigned* l_cand = sm_u + chunk;  // [chunk] flat indices of the d0 bin
+  unsigned* l_out = sm_u;        // [K] flat indices going straight to the output (fewer than K elements of the whole image
+                                 //     lie above the d0 bin, or exist at all when d0 == -1)
+  unsigned* l_cand = sm_u + K;   // [chunk] flat indices of the d0 bin (all of them, if every score of the chunk is equal)
   __shared__ int n_out, n_cand, base_out, base_cand;
   const int b = blockIdx.y;
   const int d0 = st[b].d0;
@@ -132,14 +133,30 @@ __global__ __launch_bounds__(256) void od_topk_partition(const float* __restrict
   __syncthreads();
   const int beg = blockIdx.x * chunk;
   const int end = min(beg + chunk, N);
-  for (int i = beg + threadIdx.x; i < end; i += 256) {
-    const unsigned sb = score_bits(src[i], thr);
-    if (!sb) continue;
-    const int dg = (int)((sb >> 19) & (NB - 1));
-    if (dg > d0) {  // d0 == -1: everything
-      l_out[atomicAdd(&n_out, 1)] = (unsigned)i;
-    } else if (dg == d0) {
-      l_cand[atomicAdd(&n_cand, 1)] = (unsigned)i;
+  // 16-byte loads, four per thread in flight (N and chunk are multiples of 4; one 4-byte load per trip ran this pass at
+  // 1.4 TB/s -- 32 us of the 0.2 ms post-processing chain at 32 x 320^2 -- against 4.4 TB/s for the histogram pass)
+  for (int i0 = beg + threadIdx.x * 4; i0 < end; i0 += 256 * 4 * 4) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 1024;
+      v[u] = i < end ? *(const f32x4*)(src + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 1024;
+      if (i >= end) break;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned sb = score_bits(v[u][e], thr);
+        if (!sb) continue;
+        const int dg = (int)((sb >> 19) & (NB - 1));
+        if (dg > d0) {  // d0 == -1: everything
+          l_out[atomicAdd(&n_out, 1)] = (unsigned)(i + e);
+        } else if (dg == d0) {
+          l_cand[atomicAdd(&n_cand, 1)] = (unsigned)(i + e);
+        }
+      }
     }
   }
   __syncthreads();
@@ -271,8 +288,14 @@ extern "C" int od_topk_scores(od_ctx* ctx, const float* conf, int B, int N, int 
   OD_CHECK_LAUNCH();
   hipLaunchKernelGGL(od_topk_select0, dim3(B), dim3(64), 0, s, hist, st, K);
   OD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(od_topk_partition, dim3(chunks, B), dim3(256), (size_t)chunk * 8, s, conf, N, conf_threshold, st,
-                     (unsigned long long*)keys, cand, K, chunk);
+  // its own, smaller chunk: K + chunk u32 of LDS (20 KiB at K = 1024) -> eight workgroups per CU
+  const int pchunk = chunk > 4096 ? 4096 : chunk;
+  const int pchunks = od_ceil_div(N, pchunk);
+  const size_t plds = ((size_t)K + pchunk) * sizeof(unsigned);
+  OD_REQUIRE(plds <= 160 * 1024, "od_topk_scores: K too large for the partition pass (K + 4096 u32 of LDS)");
+  if (int rc = od_ensure_lds(ctx, (const void*)&od_topk_partition, plds)) return rc;
+  hipLaunchKernelGGL(od_topk_partition, dim3(pchunks, B), dim3(256), plds, s, conf, N, conf_threshold, st,
+                     (unsigned long long*)keys, cand, K, pchunk);
   OD_CHECK_LAUNCH();
   hipLaunchKernelGGL(od_topk_refine, dim3(B), dim3(1024), 0, s, conf, N, st, (unsigned long long*)keys, cand, K);
   OD_CHECK_LAUNCH();
