@@ -69,6 +69,13 @@ for _c in range(NE8, NE8 + NE8N):
               (1, 10, 10, 64, 512, 1, 1, "elu", "same", _c),          # 1x1, ONE K tile
               (1, 8, 8, 128, 64, 1, 1, None, "none", _c),             # 1x1, two K tiles
               (3, 9, 7, 192, 208, 3, 1, "leaky", "same", _c)]         # Cin = 3 x 64, odd map
+# the streaming 3x3 kernels of the 32 <-> 64-channel layers (conv_stream3.hip; chosen by the library for these shapes)
+CASES += [(2, 16, 32, 64, 32, 3, 1, "leaky", "none", -1),     # 64 -> 32 (backward-data of b.s1.0.b), 4 x 2 tiles per image
+          (1, 8, 48, 32, 64, 3, 1, "elu", "none", -1),        # 32 -> 64 (b.s1.0.b forward), 64-byte LDS rows
+          (2, 16, 64, 32, 64, 3, 2, None, "none", -1),        # 32 -> 64 stride 2 (b.down1 forward): two-buffer ring
+          (3, 40, 64, 32, 64, 3, 2, "leaky", "none", -1),
+          (5, 44, 80, 64, 32, 3, 1, None, "none", -1),        # 55 tiles per image, 275 tiles: several ring turns per workgroup
+          (32, 160, 160, 32, 64, 3, 1, "leaky", "none", -1)]  # the training step's own shape (12 800 tiles)
 CASES += [(2, 20, 20, 512, 128, 3, 1, "leaky", "up2", NIG + 3),                                 # 8 slices
           (1, 3, 5, 64, 64, 3, 1, None, "none", NIG + 1)]                                       # map smaller than a tile
 
