@@ -368,6 +368,127 @@ __global__ __launch_bounds__(512, 2) void od_conv_wgrad_w8(WgradKP p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Thin form for the 160x160 / 320x320 maps: Cin = 32, Cout = 64, 3x3 (b.down1, b.s1.0.b): the whole 64 x 288 gradient is ONE
+// tile, the reduction runs over 0.8 M pixels, and the layer is a stream of dZ (105 MB) and X (52 / 210 MB).  On the 128 x 128
+// kernel above it is 3 column tiles x 171 pixel splits that each re-stage dZ and gather X tap by tap (9 x the bytes) at 37 %
+// tile use: 150-165 us.  Here: persistent workgroups (4 waves as 2 x 2: 32 channels x 144 columns per wave = 18 accumulator
+// fragments), a chunk = 32 consecutive output pixels of one row: its dZ rows (4 KiB, contiguous) and the three input row
+// segments it touches (34 or 65 pixels x 64 B each, contiguous) arrive by LDS-DMA into a 3-deep ring (counted vmcnt, one
+// raw barrier per chunk); every tap is a row offset into those segments for the transposing LDS read.  One f32 slab per
+// workgroup, summed by od_wgrad_reduce_multi in its fixed order.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int S>
+struct ThinCfg {
+  static constexpr int NPX = 31 * S + 3;                  // input pixels per row segment: 34 (stride 1) / 65 (stride 2)
+  static constexpr int XPIECES = (NPX + 15) / 16;         // 1-KiB pieces (16 pixels x 64 B) per segment: 3 / 5
+  static constexpr int XSLOTS = XPIECES * 16;
+  static constexpr int PIECES = (4 + 3 * XPIECES + 3) / 4 * 4;  // dZ 4 + X 3 segments, padded to the 4 waves: 16 / 20
+  static constexpr int ND = PIECES / 4;
+  static constexpr int BUF = PIECES * 1024;
+  static constexpr int LDS = 3 * BUF;
+};
+
+template <int S>
+__global__ __launch_bounds__(256, 2) void od_conv_wgrad_thin(WgradKP p, int chunks_per_row, int nchunks) {
+  using Cf = ThinCfg<S>;
+  extern __shared__ __attribute__((aligned(16))) char tsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int tq = l15 >> 2, tp = l15 & 3;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // piece k of a chunk: 0-3 = dZ (8 pixels x 128 B each), then segment dy = 0..2 with XPIECES pieces of 16 pixels x 64 B,
+  // then padding pieces (zero page) so that every wave issues ND per chunk
+  auto stage = [&](int chunk, int buf) {
+    const int row = chunk / chunks_per_row, ox0 = (chunk - row * chunks_per_row) * 32;
+    const int b = row / p.Ho, oy = row - b * p.Ho;
+    char* base = tsm + buf * Cf::BUF;
+#pragma unroll
+    for (int k = 0; k < Cf::ND; ++k) {
+      const int piece = wave + 4 * k;
+      const f16* src = p.zero;
+      if (piece < 4) {
+        src = p.dz + (((long long)row * p.Wo + ox0) * 64 + piece * 512 + lane * 8);
+      } else if (piece < 4 + 3 * Cf::XPIECES) {
+        const int sp = piece - 4;
+        const int dy = sp / Cf::XPIECES, q = (sp - dy * Cf::XPIECES) * 16 + (lane >> 2);  // pixel slot inside the segment
+        const int iy = oy * S + dy - 1, ix = ox0 * S - 1 + q;
+        if (q < Cf::NPX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          src = p.x + ((((long long)b * p.H + iy) * p.W + ix) * 32 + (lane & 3) * 8);
+      }
+      glds16(src, base + piece * 1024);
+    }
+  };
+
+  f32x4 acc[2][9];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int c = 0; c < 9; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int first = blockIdx.x, step = gridDim.x;
+  const int nmine = first < nchunks ? (nchunks - first + step - 1) / step : 0;
+  if (nmine > 0) stage(first, 0);
+  if (nmine > 1) stage(first + step, 1);
+  for (int it = 0; it < nmine; ++it) {
+    // chunk `it` landed: at most the ND pieces of chunk it+1 stay in flight
+    if (it + 1 < nmine) {
+      wait_vmcnt<Cf::ND>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (it + 2 < nmine) stage(first + (it + 2) * step, (it + 2) % 3);
+    const char* db = tsm + (it % 3) * Cf::BUF;  // dZ: [32 pixels][64 channels], 128-B rows
+    const char* xb = db + 4096;                 // X: 3 segments of XSLOTS pixels, 64-B rows
+    f16x8 af[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int unit = (2 * wr + i) * 4 + tp;  // 8-byte unit inside the 128-B row: 16 channels = 4 units
+      h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+          (__attribute__((address_space(3))) h4*)(db + (8 * lq + tq) * 128 + unit * 8));
+      h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+          (__attribute__((address_space(3))) h4*)(db + (8 * lq + 4 + tq) * 128 + unit * 8));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        af[i][e] = (f16)lo[e];
+        af[i][4 + e] = (f16)hi[e];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const int cf = wc * 9 + c;            // column fragment 0..17 = (tap, 16-channel half)
+      const int tap = cf >> 1, half = cf & 1;
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const char* seg = xb + dy * (Cf::XSLOTS * 64);
+      h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+          (__attribute__((address_space(3))) h4*)(seg + (S * (8 * lq + tq) + dx) * 64 + (half * 4 + tp) * 8));
+      h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+          (__attribute__((address_space(3))) h4*)(seg + (S * (8 * lq + 4 + tq) + dx) * 64 + (half * 4 + tp) * 8));
+      f16x8 bf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bf[e] = (f16)lo[e];
+        bf[4 + e] = (f16)hi[e];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf, acc[i][c], 0, 0, 0);
+    }
+  }
+  // acc[i][c][e] = D[channel (2*wr + i)*16 + lq*4 + e][column (wc*9 + c)*16 + l15]
+  float* slab = p.slabs + (long long)blockIdx.x * 64 * 288;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int c = 0; c < 9; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        slab[((2 * wr + i) * 16 + lq * 4 + e) * 288 + (wc * 9 + c) * 16 + l15] = acc[i][c][e];
+}
+
 }  // namespace
 
 // pixel split of the 256-wide kernel: one 512-thread workgroup per CU, one round (tiles x split <= CUs), and at least 12
@@ -408,6 +529,20 @@ static bool wgrad_use_w8(int cus, int M, int Cout, int Ktot) {
     min_wgs = e ? atoi(e) : 160;
   }
   return eff >= 0.74 && tiles * split >= min_wgs;
+}
+
+// the thin kernel's shapes (slab output only): 3x3, 32 -> 64 channels, output rows that are whole 32-pixel chunks
+static bool wgrad_thin_ok(int Cin, int Cout, int ksize, int stride, int H, int W, int Ho, int Wo) {
+  static int allow = -1;
+  if (allow < 0) {
+    const char* e = getenv("OD_WGRAD_THIN");  // 0 = the 128 x 128 kernel (A/B timing)
+    allow = e ? atoi(e) : 1;
+  }
+  return allow && Cin == 32 && Cout == 64 && ksize == 3 && Wo % 32 == 0 && H == Ho * stride && W == Wo * stride;
+}
+static int wgrad_thin_grid(const od_ctx* ctx, long long nchunks) {
+  long long g = 2LL * (ctx->num_cu > 0 ? ctx->num_cu : 256);
+  return (int)(g < nchunks ? g : nchunks);
 }
 
 static int wgrad_split(const od_ctx* ctx, int M, int Cout, int Ktot, int* chunks_per_split) {
@@ -455,6 +590,19 @@ static int wgrad_impl(od_ctx* ctx, const void* x, const void* dz, float* dw, flo
   OD_REQUIRE(M64 * Cout < (1LL << 31) && (long long)B * H * W * Cin < (1LL << 31), "od_conv2d_bwd_weight: too large");
   p.M = (int)M64;
   p.HoWo = p.Ho * p.Wo;
+  if (slabs && wgrad_thin_ok(Cin, Cout, ksize, stride, H, W, p.Ho, p.Wo)) {
+    const int nchunks = p.M / 32;
+    const int grid = wgrad_thin_grid(ctx, nchunks);
+    p.split = grid;
+    if (nsplit) *nsplit = grid;
+    const void* fn = stride == 1 ? (const void*)&od_conv_wgrad_thin<1> : (const void*)&od_conv_wgrad_thin<2>;
+    const size_t lds = stride == 1 ? (size_t)ThinCfg<1>::LDS : (size_t)ThinCfg<2>::LDS;
+    if (int rc = od_ensure_lds(ctx, fn, lds)) return rc;
+    int cpr = p.Wo / 32, nch = nchunks;
+    void* args[] = {&p, &cpr, &nch};
+    OD_CHECK_HIP(hipLaunchKernel(fn, dim3(grid), dim3(256), args, lds, (hipStream_t)stream));
+    return OD_OK;
+  }
   p.split = wgrad_split(ctx, p.M, Cout, p.Ktot, &p.chunks_per_split);
   if (nsplit) *nsplit = p.split;
   if (wgrad_use_w8(ctx->num_cu > 0 ? ctx->num_cu : 256, p.M, Cout, p.Ktot)) {
@@ -487,7 +635,9 @@ extern "C" int od_conv2d_bwd_weight_splits(od_ctx* ctx, int B, int H, int W, int
   if (!ctx || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2))
     return 0;
   const int pad = ksize / 2;
-  const long long M = (long long)B * ((H + 2 * pad - ksize) / stride + 1) * ((W + 2 * pad - ksize) / stride + 1);
+  const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+  const long long M = (long long)B * Ho * Wo;
+  if (wgrad_thin_ok(Cin, Cout, ksize, stride, H, W, Ho, Wo)) return wgrad_thin_grid(ctx, M / 32);  // slabs of od_conv2d_bwd_weight_slabs
   return wgrad_split(ctx, (int)M, Cout, ksize * ksize * Cin, nullptr);
 }
 

@@ -187,7 +187,11 @@ def test_bn_fold_bit_exact_vs_numpy(cuda):
 
 
 @pytest.mark.parametrize("case", [(8, 40, 40, 128, 256, 3, 1), (4, 20, 20, 256, 512, 3, 1), (32, 10, 10, 512, 1024, 3, 1),
-                                  (4, 40, 40, 256, 512, 3, 2), (16, 40, 40, 256, 128, 1, 1)], ids=str)
+                                  (4, 40, 40, 256, 512, 3, 2), (16, 40, 40, 256, 128, 1, 1),
+                                  # the thin kernel (32 -> 64 channels, rows of whole 32-pixel chunks): stride 1 and 2, one
+                                  # chunk per workgroup up to several ring turns
+                                  (2, 8, 32, 32, 64, 3, 1), (3, 12, 64, 32, 64, 3, 1), (2, 16, 64, 32, 64, 3, 2),
+                                  (5, 40, 128, 32, 64, 3, 2), (16, 160, 160, 32, 64, 3, 1)], ids=str)
 def test_weight_gradient_slab_path_many_splits(cuda, case):
     """The form the trainer uses: per-split f32 slabs (plain stores) + fixed-order reduce, at sizes where the pixel range is
     split over many workgroups (33 splits of the 256-wide kernel on the first case).  vs torch conv2d weight gradient in
