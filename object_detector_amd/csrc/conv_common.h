@@ -294,6 +294,9 @@ bool od_conv_win_select(int idx, const ConvKP& p, ConvKernelInfo* info, size_t* 
 // conv_tconv.hip: streaming backward-data kernel of the first stride-2 convolution (dZ 64 channels -> dX 32 channels)
 bool od_tconv_small_supported(const od_conv_desc* d);
 int od_tconv_small_launch(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, const char** kernel_name, bool dry_run);
+// conv_rdirect.hip: 3x3, 64 -> 128 channels on large maps: all weights in LDS, pixel operand straight from global memory
+bool od_conv_rdirect_supported(const od_conv_desc* d);
+int od_conv_rdirect_launch(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, const char** kernel_name, bool dry_run);
 // conv_stream3.hip: streaming 3x3 kernels of the 32 <-> 64-channel layers on the largest maps
 bool od_conv_stream3_supported(const od_conv_desc* d);
 int od_conv_stream3_launch(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, const char** kernel_name, bool dry_run);

@@ -1,0 +1,218 @@
+// K1r: 3x3 stride-2 convolution 64 -> 128 channels on a large map (`b.down2`: 160x160 -> 80x80 at 320^2) with
+// ALL weights resident in LDS and the pixel operand read straight from global memory into registers.
+//
+// The layer moves 157 MB for 30 GFLOP and is HBM-bound; on the table kernels it costs 76-79 us against 35 us of traffic
+// (short K: 9 K steps per tile, thousands of workgroups in their prologue).  The streaming kernels of
+// conv_stream3.hip keep nine weight taps of a 32 <-> 64-channel layer (36 KiB) next to a window ring; here the nine taps are
+// 147 KiB, so there is no room for a window -- and none is needed: a lane's MFMA operand for tap (dy, dx) is 16 contiguous
+// bytes of ONE input pixel (8 channels), i.e. one global_load_dwordx4; the 2.25 (stride 2) or 9 (stride 1) loads that touch
+// the same pixel hit L1 / L2.  One workgroup per CU (8 waves, 147 KiB of weights loaded once), every wave walks its own
+// 16-pixel row segments (item = wave index + k x total waves) with the next item's 18 loads in flight, 144 MFMAs per item
+// (weights from LDS, conflict-free ds_read_b128), no barrier after the weights have landed; epilogue = scale / bias /
+// activation from the accumulators, 16-byte stores (v_permlane16_swap pairing, as conv_8ph.hip).
+//
+// Replaces Conv2D + BatchNormalization + LeakyReLU of `b.down2` inside `ObjectDetector.predict` (reference
+// voc_validate.py:27; docs/MODEL.md:15-17) and the same layers' forward in training.
+#include <stdlib.h>
+
+#include "conv_common.h"
+
+namespace {
+
+struct RdKP {
+  const f16* x;      // [B, H, W, KC]
+  const f16* w;      // packed [256][9*KC]: row n, k = tap*KC + c
+  const float* scale;
+  const float* bias;
+  f16* out;          // [B, Ho, Wo, NC]
+  int H, W, Ho, Wo, Kstride;
+  int act;
+  float alpha;
+  int segs_per_row, nitems;
+};
+
+template <int KC, int NC, int S>
+__global__ __launch_bounds__(512, 2) void od_conv_rdirect(RdKP p) {
+  constexpr int ROWB = KC * 2;             // bytes per weight row (one tap, one output channel)
+  constexpr int CH = ROWB / 16;            // 16-byte chunks per row
+  constexpr int KH = KC / 32;              // MFMA k steps per tap
+  constexpr int NF = NC / 16;              // output-channel fragments
+  constexpr int WROWS = 9 * NC;
+  extern __shared__ __attribute__((aligned(16))) char wlds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  // ---- all weights -> LDS: row r = tap*NC + n, chunk c stored at c ^ (r & 7) (low 3 bits) -----------------------------
+  {
+    constexpr int LPR = CH;                 // lanes per row in a 1-KiB piece
+    constexpr int RPP = 64 / LPR;           // rows per piece
+    constexpr int PIECES = WROWS / RPP;     // 144 (KC = 64)
+    for (int q = wave; q < PIECES; q += 8) {
+      const int r = q * RPP + lane / LPR;
+      const int tap = r / NC, n = r - tap * NC;
+      const int pc = lane % LPR;
+      const int lc = (pc & ~7) | ((pc ^ r) & 7);
+      glds16(p.w + ((long long)n * p.Kstride + tap * KC + lc * 8), wlds + q * 1024);
+    }
+  }
+
+  // this lane's operand loads of one item: pixel (oy*S + dy - 1, (ox0 + l15)*S + dx - 1), channels kh*32 + lq*8 .. +7
+  auto load_item = [&](int item, f16x8 (&xs)[9][KH]) {
+    const int row = item / p.segs_per_row, ox0 = (item - row * p.segs_per_row) * 16;
+    const int b = row / p.Ho, oy = row - b * p.Ho;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = oy * S + dy - 1;
+      const bool yok = (unsigned)iy < (unsigned)p.H;
+      const f16* rowp = p.x + ((long long)(b * p.H + iy) * p.W) * KC + lq * 8;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = (ox0 + l15) * S + dx - 1;
+        const bool ok = yok && (unsigned)ix < (unsigned)p.W;
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+          f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (ok) v = *(const f16x8*)(rowp + (long long)ix * KC + kh * 32);
+          xs[dy * 3 + dx][kh] = v;
+        }
+      }
+    }
+  };
+
+  const int n8 = (lq & 1) * 16 + (lq >> 1) * 8;  // this lane's 8 channels inside a 32-channel store group
+  const int gw = blockIdx.x * 8 + wave, nw = gridDim.x * 8;
+  f16x8 xa[9][KH], xb[9][KH];
+  int item = gw;
+  if (item < p.nitems) load_item(item, xa);
+  // scale / bias -> LDS behind the weights (read per item; 64 more registers would not fit beside two operand sets)
+  float* const sb = (float*)(wlds + WROWS * ROWB);
+  if (tid < NC) {
+    sb[tid] = p.scale[tid];
+    sb[NC + tid] = p.bias[tid];
+  }
+  wait_vmcnt<0>();  // every weight piece has landed (a counted wait cannot be used: border items issue fewer operand loads)
+  __syncthreads();
+
+  // weight fragment address: row tap*NC + f*16 + l15, chunk (kh*4 + lq) ^ (l15 & 7)  [row & 7 == l15 & 7: NC % 8 == 0]
+  const int fw = l15 * ROWB + ((lq ^ (l15 & 7)) * 16);
+
+  auto compute_store = [&](int it, f16x8 (&xs)[9][KH]) {
+    f32x4 acc[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const f16x8 wv = *(const f16x8*)(wlds + (tap * NC + f * 16) * ROWB + (fw ^ (kh * 64)));
+          acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xs[tap][kh], acc[f], 0, 0, 0);
+        }
+    od_mfma_results_ready();
+    const int row = it / p.segs_per_row, ox0 = (it - row * p.segs_per_row) * 16;
+    f16* orow = p.out + ((long long)row * p.Wo + ox0 + l15) * NC + n8;
+#pragma unroll
+    for (int s = 0; s < NC / 32; ++s) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = acc[2 * s][e], b = acc[2 * s + 1][e];
+        od_permlane16_swap(a, b);
+        o[e] = a;
+        o[4 + e] = b;
+      }
+      const f32x4 s0 = *(const f32x4*)(sb + s * 32 + n8), s1 = *(const f32x4*)(sb + s * 32 + n8 + 4);
+      const f32x4 b0 = *(const f32x4*)(sb + NC + s * 32 + n8), b1 = *(const f32x4*)(sb + NC + s * 32 + n8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = o[e] * s0[e] + b0[e];
+        o[4 + e] = o[4 + e] * s1[e] + b1[e];
+      }
+      if (p.act == OD_ACT_LEAKY) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = od_leaky(o[e], p.alpha);
+      } else if (p.act == OD_ACT_ELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = o[e] > 0.f ? o[e] : p.alpha * od_expm1_fast(o[e]);
+      }
+      f16x8 h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] = (f16)o[e];
+      *(f16x8*)(orow + s * 32) = h;
+    }
+  };
+
+  // two items per trip so that the operand sets stay in fixed registers (xa: even items, xb: odd items)
+  while (item < p.nitems) {
+    const int n1 = item + nw;
+    if (n1 < p.nitems) load_item(n1, xb);
+    compute_store(item, xa);
+    if (n1 >= p.nitems) break;
+    const int n2 = n1 + nw;
+    if (n2 < p.nitems) load_item(n2, xa);
+    compute_store(n1, xb);
+    item = n2;
+  }
+}
+
+struct RdEntry {
+  int kc, nc, stride;
+  const void* fn;
+  const char* name;
+  size_t lds;
+};
+const RdEntry g_rd[] = {
+    {64, 128, 2, (const void*)&od_conv_rdirect<64, 128, 2>, "od_conv_rdirect<64, 128, 2>", (size_t)9 * 128 * 128 + 1024},
+    // (stride 1 -- b.s2.*.b in training -- is instantiable but not offered: there every pixel is loaded nine times and the
+    //  kernel is L1-bound, 60-63 us against 58-59 us on the table kernel; stride 2 loads a pixel 2.25 times: 76 -> 54 us)
+};
+const RdEntry* rd_find(const od_conv_desc* d) {
+  for (const RdEntry& e : g_rd)
+    if (e.kc == d->Cin && e.nc == d->Cout && e.stride == d->stride) return &e;
+  return nullptr;
+}
+
+}  // namespace
+
+bool od_conv_rdirect_supported(const od_conv_desc* d) {
+  if (d->transposed || d->ksize != 3 || d->res_mode != OD_RES_NONE || d->out_dtype != OD_DT_F16 || d->out_batch_stride != 0 ||
+      d->out_pix_stride != 0 || d->bn_partials || d->w2 || d->H % d->stride || d->W % d->stride)
+    return false;
+  const int Wo = d->W / d->stride;
+  if (rd_find(d) == nullptr || Wo % 16 != 0 || (long long)d->B * d->H * d->W * d->Cin >= (1LL << 31)) return false;
+  // large maps only: the 147 KiB of weights are loaded once per workgroup (OD_CONV_RDIRECT_MIN_PIXELS overrides: tests)
+  long long min_px = 1 << 18;
+  if (const char* e = getenv("OD_CONV_RDIRECT_MIN_PIXELS")) min_px = atoll(e);
+  return (long long)d->B * d->H * d->W >= min_px;
+}
+
+int od_conv_rdirect_launch(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, const char** kernel_name, bool dry_run) {
+  const RdEntry* e = rd_find(d);
+  if (!e) return OD_ERR_INVALID;
+  if (kernel_name) *kernel_name = e->name;
+  if (dry_run) return OD_OK;
+  RdKP p;
+  p.x = (const f16*)d->x;
+  p.w = (const f16*)d->w;
+  p.scale = d->scale;
+  p.bias = d->bias;
+  p.out = (f16*)d->out;
+  p.H = d->H;
+  p.W = d->W;
+  p.Ho = d->H / d->stride;
+  p.Wo = d->W / d->stride;
+  p.Kstride = od_round_up(9 * d->Cin, 64);
+  p.act = d->act;
+  p.alpha = d->alpha;
+  p.segs_per_row = p.Wo / 16;
+  p.nitems = d->B * p.Ho * p.segs_per_row;
+  const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
+  int grid = cus;
+  if (grid * 8 > p.nitems) grid = od_ceil_div(p.nitems, 8);
+  if (int rc = od_ensure_lds(ctx, e->fn, e->lds)) return rc;
+  void* args[] = {&p};
+  OD_CHECK_HIP(hipLaunchKernel(e->fn, dim3(grid), dim3(512), args, e->lds, stream));
+  return OD_OK;
+}

@@ -115,6 +115,40 @@ def test_conv_matches_oracle(cuda, case):
     assert (err <= tol).all(), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
 
 
+RDIRECT_CASES = [(2, 16, 32, 2, "leaky"), (1, 8, 32, 2, "elu"), (3, 24, 96, 2, None), (2, 26, 64, 2, "leaky"),
+                 (4, 160, 160, 2, "leaky")]
+
+
+@pytest.mark.parametrize("case", RDIRECT_CASES, ids=str)
+def test_conv_64_to_128_weights_resident_kernel(cuda, case, monkeypatch):
+    """od_conv_rdirect (conv_rdirect.hip): 3x3, 64 -> 128 channels, all nine weight taps in LDS, the pixel operand read
+    straight from global memory -- what od_conv2d_fwd picks for `b.down2` (stride 2) on large maps (the size threshold is
+    lifted here so that small maps reach it too).  vs the f64 oracle like every other config, and vs the table kernel the
+    library would otherwise take (same inputs: equal to 1 f16 ulp + accumulation-order noise)."""
+    from object_detector_amd import ops
+    monkeypatch.setenv("OD_CONV_RDIRECT_MIN_PIXELS", "0")
+    B, H, W, stride, act = case
+    Cin, Cout, k = 64, 128, 3
+    rng = np.random.default_rng(hash(case) & 0xFFFF)
+    x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float16)
+    w = (rng.normal(0, 1, (Cout, k, k, Cin)) * np.sqrt(2.0 / (k * k * Cin))).astype(np.float16)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    bias = rng.normal(0, 0.1, Cout).astype(np.float32)
+    alpha = 0.1 if act == "leaky" else 1.0
+    xt = torch.from_numpy(x).to(cuda)
+    out = ops.conv2d(xt, w.astype(np.float32), scale, bias, stride=stride, act=act, alpha=alpha, tile_cfg=-1)
+    gen = ops.conv2d(xt, w.astype(np.float32), scale, bias, stride=stride, act=act, alpha=alpha, tile_cfg=2)
+    torch.cuda.synchronize()
+    got, g = out.cpu().numpy().astype(np.float64), gen.cpu().numpy().astype(np.float64)
+    tolg = 1e-3 * max(1.0, np.abs(g).max()) + 2.0 ** -10 * np.abs(g)
+    assert (np.abs(got - g) <= tolg).all(), f"vs table kernel: max {np.abs(got - g).max()}"
+    if B * H * W <= 20000:  # the f64 oracle on the CPU
+        ref = _ref(x.astype(np.float32), w.astype(np.float32), scale, bias, stride, act, alpha)
+        err = np.abs(got - ref)
+        tol = 1e-3 * max(1.0, np.abs(ref).max()) + 2.0 ** -10 * np.abs(ref)
+        assert got.shape == ref.shape and (err <= tol).all(), f"max err {err.max()}"
+
+
 PW_CASES = []
 for _c in range(NE8, NE8 + NE8N):  # every BM of the 8-wave kernel: the second layer runs in the epilogue
     PW_CASES += [(2, 20, 20, 128, 256, 3, 1, "leaky", "same", "leaky", _c),   # stage-3 block: 3x3 + residual, then the next 1x1
