@@ -148,7 +148,8 @@ __global__ __launch_bounds__(256) void od_conv_first_wgrad_finish(const float* _
 // window of a chunk lives in L1), 4 v_mfma_f32_16x16x32_f16.  Every wave walks its own chunks (chunk = wave index + k *
 // total waves) with the next chunk's loads in flight, keeps the 32 x 32 f32 sums in 16 registers, the four waves of a
 // workgroup are added in order through LDS, one [32][32] slab per workgroup, od_conv_first_wgrad_finish2 adds the slabs in
-// a fixed order.  224 -> 60 us at 32 x 320^2 (the widening pass + the generic kernel at 14 % tile use + finish before).
+// a fixed order.  224 -> 95 us at 32 x 320^2 (the widening pass + the generic kernel at 14 % tile use + finish before; the
+// byte loads, 16 vector-memory instructions per chunk and wave, are what bounds it now).
 typedef __fp16 h4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 __global__ __launch_bounds__(256) void od_conv_first_wgrad_stream(const uint8_t* __restrict__ x, const f16* __restrict__ dz,
