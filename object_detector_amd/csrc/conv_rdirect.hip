@@ -25,19 +25,30 @@ struct RdKP {
   const float* scale;
   const float* bias;
   f16* out;          // [B, Ho, Wo, NC]
+  const f16* res;    // residual [B, Ho, Wo, NC] added after the activation (OD_RES_SAME), or null
   int H, W, Ho, Wo, Kstride;
   int act;
   float alpha;
   int segs_per_row, nitems;
 };
 
-template <int KC, int NC, int S>
+// 16-byte chunk swizzle of a weight row: 128-B and longer rows XOR the low 3 chunk bits with the row's low 3 bits, 64-B rows
+// (4 chunks) with bits 1-2 of the row; every fragment read (16 consecutive rows, one chunk column) is then conflict-free
+template <int CH>
+__device__ __forceinline__ int rd_swz(int chunk, int row) {
+  return CH >= 8 ? ((chunk & ~7) | ((chunk ^ row) & 7)) : (chunk ^ ((row >> 1) & 3));
+}
+
+// KS = 3: the 3x3 layer described above.  KS = 1: the pointwise layers of the 160x160 / 80x80 maps in training (weights
+// <= 16 KiB, a pixel is loaded exactly once): pure streams that the table kernels run at 60-75 % of what HBM gives.
+template <int KC, int NC, int S, int KS>
 __global__ __launch_bounds__(512, 2) void od_conv_rdirect(RdKP p) {
   constexpr int ROWB = KC * 2;             // bytes per weight row (one tap, one output channel)
   constexpr int CH = ROWB / 16;            // 16-byte chunks per row
   constexpr int KH = KC / 32;              // MFMA k steps per tap
   constexpr int NF = NC / 16;              // output-channel fragments
-  constexpr int WROWS = 9 * NC;
+  constexpr int TAPS = KS * KS, PAD = KS / 2;
+  constexpr int WROWS = TAPS * NC;
   extern __shared__ __attribute__((aligned(16))) char wlds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -47,34 +58,34 @@ __global__ __launch_bounds__(512, 2) void od_conv_rdirect(RdKP p) {
   {
     constexpr int LPR = CH;                 // lanes per row in a 1-KiB piece
     constexpr int RPP = 64 / LPR;           // rows per piece
-    constexpr int PIECES = WROWS / RPP;     // 144 (KC = 64)
+    constexpr int PIECES = (WROWS + RPP - 1) / RPP;  // 144 (3x3, KC = 64, NC = 128)
     for (int q = wave; q < PIECES; q += 8) {
-      const int r = q * RPP + lane / LPR;
+      int r = q * RPP + lane / LPR;
+      if (r >= WROWS) r = WROWS - 1;  // (a last, partial piece re-writes the last row with itself)
       const int tap = r / NC, n = r - tap * NC;
-      const int pc = lane % LPR;
-      const int lc = (pc & ~7) | ((pc ^ r) & 7);
+      const int lc = rd_swz<CH>(lane % LPR, r);
       glds16(p.w + ((long long)n * p.Kstride + tap * KC + lc * 8), wlds + q * 1024);
     }
   }
 
   // this lane's operand loads of one item: pixel (oy*S + dy - 1, (ox0 + l15)*S + dx - 1), channels kh*32 + lq*8 .. +7
-  auto load_item = [&](int item, f16x8 (&xs)[9][KH]) {
+  auto load_item = [&](int item, f16x8 (&xs)[TAPS][KH]) {
     const int row = item / p.segs_per_row, ox0 = (item - row * p.segs_per_row) * 16;
     const int b = row / p.Ho, oy = row - b * p.Ho;
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int iy = oy * S + dy - 1;
+    for (int dy = 0; dy < KS; ++dy) {
+      const int iy = oy * S + dy - PAD;
       const bool yok = (unsigned)iy < (unsigned)p.H;
       const f16* rowp = p.x + ((long long)(b * p.H + iy) * p.W) * KC + lq * 8;
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int ix = (ox0 + l15) * S + dx - 1;
+      for (int dx = 0; dx < KS; ++dx) {
+        const int ix = (ox0 + l15) * S + dx - PAD;
         const bool ok = yok && (unsigned)ix < (unsigned)p.W;
 #pragma unroll
         for (int kh = 0; kh < KH; ++kh) {
           f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
           if (ok) v = *(const f16x8*)(rowp + (long long)ix * KC + kh * 32);
-          xs[dy * 3 + dx][kh] = v;
+          xs[dy * KS + dx][kh] = v;
         }
       }
     }
@@ -82,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void od_conv_rdirect(RdKP p) {
 
   const int n8 = (lq & 1) * 16 + (lq >> 1) * 8;  // this lane's 8 channels inside a 32-channel store group
   const int gw = blockIdx.x * 8 + wave, nw = gridDim.x * 8;
-  f16x8 xa[9][KH], xb[9][KH];
+  f16x8 xa[TAPS][KH], xb[TAPS][KH];
   int item = gw;
   if (item < p.nitems) load_item(item, xa);
   // scale / bias -> LDS behind the weights (read per item; 64 more registers would not fit beside two operand sets)
@@ -94,25 +105,34 @@ __global__ __launch_bounds__(512, 2) void od_conv_rdirect(RdKP p) {
   wait_vmcnt<0>();  // every weight piece has landed (a counted wait cannot be used: border items issue fewer operand loads)
   __syncthreads();
 
-  // weight fragment address: row tap*NC + f*16 + l15, chunk (kh*4 + lq) ^ (l15 & 7)  [row & 7 == l15 & 7: NC % 8 == 0]
-  const int fw = l15 * ROWB + ((lq ^ (l15 & 7)) * 16);
+  // weight fragment address: row tap*NC + f*16 + l15 (its swizzle key depends on l15 only: NC and 16 are multiples of 16),
+  // chunk kh*4 + lq
+  int fwk[KH];
+#pragma unroll
+  for (int kh = 0; kh < KH; ++kh) fwk[kh] = l15 * ROWB + rd_swz<CH>(kh * 4 + lq, l15) * 16;
 
-  auto compute_store = [&](int it, f16x8 (&xs)[9][KH]) {
+  auto compute_store = [&](int it, f16x8 (&xs)[TAPS][KH]) {
     f32x4 acc[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
       for (int kh = 0; kh < KH; ++kh)
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-          const f16x8 wv = *(const f16x8*)(wlds + (tap * NC + f * 16) * ROWB + (fw ^ (kh * 64)));
+          const f16x8 wv = *(const f16x8*)(wlds + (tap * NC + f * 16) * ROWB + fwk[kh]);
           acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xs[tap][kh], acc[f], 0, 0, 0);
         }
     od_mfma_results_ready();
     const int row = it / p.segs_per_row, ox0 = (it - row * p.segs_per_row) * 16;
-    f16* orow = p.out + ((long long)row * p.Wo + ox0 + l15) * NC + n8;
+    const long long ooff = ((long long)row * p.Wo + ox0 + l15) * NC + n8;
+    f16* orow = p.out + ooff;
+    f16x8 rv[NC / 32];
+    if (p.res) {
+#pragma unroll
+      for (int s = 0; s < NC / 32; ++s) rv[s] = *(const f16x8*)(p.res + ooff + s * 32);
+    }
 #pragma unroll
     for (int s = 0; s < NC / 32; ++s) {
       float o[8];
@@ -137,6 +157,10 @@ __global__ __launch_bounds__(512, 2) void od_conv_rdirect(RdKP p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = o[e] > 0.f ? o[e] : p.alpha * od_expm1_fast(o[e]);
       }
+      if (p.res) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += (float)rv[s][e];
+      }
       f16x8 h;
 #pragma unroll
       for (int e = 0; e < 8; ++e) h[e] = (f16)o[e];
@@ -158,32 +182,35 @@ __global__ __launch_bounds__(512, 2) void od_conv_rdirect(RdKP p) {
 }
 
 struct RdEntry {
-  int kc, nc, stride;
+  int kc, nc, stride, ks;
   const void* fn;
   const char* name;
   size_t lds;
 };
+#define OD_RD1(KC, NC) \
+  { KC, NC, 1, 1, (const void*)&od_conv_rdirect<KC, NC, 1, 1>, "od_conv_rdirect<" #KC ", " #NC ", 1, 1>", (size_t)NC * KC * 2 + 1024 }
 const RdEntry g_rd[] = {
-    {64, 128, 2, (const void*)&od_conv_rdirect<64, 128, 2>, "od_conv_rdirect<64, 128, 2>", (size_t)9 * 128 * 128 + 1024},
+    {64, 128, 2, 3, (const void*)&od_conv_rdirect<64, 128, 2, 3>, "od_conv_rdirect<64, 128, 2, 3>", (size_t)9 * 128 * 128 + 1024},
+    OD_RD1(64, 32), OD_RD1(32, 64), OD_RD1(128, 64), OD_RD1(64, 128),  // the pointwise layers of stages 1-2 (training)
     // (stride 1 -- b.s2.*.b in training -- is instantiable but not offered: there every pixel is loaded nine times and the
     //  kernel is L1-bound, 60-63 us against 58-59 us on the table kernel; stride 2 loads a pixel 2.25 times: 76 -> 54 us)
 };
 const RdEntry* rd_find(const od_conv_desc* d) {
   for (const RdEntry& e : g_rd)
-    if (e.kc == d->Cin && e.nc == d->Cout && e.stride == d->stride) return &e;
+    if (e.kc == d->Cin && e.nc == d->Cout && e.stride == d->stride && e.ks == d->ksize) return &e;
   return nullptr;
 }
 
 }  // namespace
 
 bool od_conv_rdirect_supported(const od_conv_desc* d) {
-  if (d->transposed || d->ksize != 3 || d->res_mode != OD_RES_NONE || d->out_dtype != OD_DT_F16 || d->out_batch_stride != 0 ||
-      d->out_pix_stride != 0 || d->bn_partials || d->w2 || d->H % d->stride || d->W % d->stride)
+  if (d->transposed || (d->res_mode != OD_RES_NONE && d->res_mode != OD_RES_SAME) || d->out_dtype != OD_DT_F16 ||
+      d->out_batch_stride != 0 || d->out_pix_stride != 0 || d->bn_partials || d->w2 || d->H % d->stride || d->W % d->stride)
     return false;
   const int Wo = d->W / d->stride;
   if (rd_find(d) == nullptr || Wo % 16 != 0 || (long long)d->B * d->H * d->W * d->Cin >= (1LL << 31)) return false;
   // large maps only: the 147 KiB of weights are loaded once per workgroup (OD_CONV_RDIRECT_MIN_PIXELS overrides: tests)
-  long long min_px = 1 << 18;
+  long long min_px = d->ksize == 3 ? (1 << 18) : (1 << 16);  // (the pointwise forms load at most 16 KiB of weights)
   if (const char* e = getenv("OD_CONV_RDIRECT_MIN_PIXELS")) min_px = atoll(e);
   return (long long)d->B * d->H * d->W >= min_px;
 }
@@ -199,17 +226,18 @@ int od_conv_rdirect_launch(od_ctx* ctx, const od_conv_desc* d, hipStream_t strea
   p.scale = d->scale;
   p.bias = d->bias;
   p.out = (f16*)d->out;
+  p.res = d->res_mode == OD_RES_SAME ? (const f16*)d->res : nullptr;
   p.H = d->H;
   p.W = d->W;
   p.Ho = d->H / d->stride;
   p.Wo = d->W / d->stride;
-  p.Kstride = od_round_up(9 * d->Cin, 64);
+  p.Kstride = od_round_up(d->ksize * d->ksize * d->Cin, 64);
   p.act = d->act;
   p.alpha = d->alpha;
   p.segs_per_row = p.Wo / 16;
   p.nitems = d->B * p.Ho * p.segs_per_row;
   const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
-  int grid = cus;
+  int grid = d->ksize == 1 ? 2 * cus : cus;  // (the 3x3 form holds 147 KiB of LDS: one workgroup per CU)
   if (grid * 8 > p.nitems) grid = od_ceil_div(p.nitems, 8);
   if (int rc = od_ensure_lds(ctx, e->fn, e->lds)) return rc;
   void* args[] = {&p};

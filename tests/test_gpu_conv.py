@@ -115,35 +115,43 @@ def test_conv_matches_oracle(cuda, case):
     assert (err <= tol).all(), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
 
 
-RDIRECT_CASES = [(2, 16, 32, 2, "leaky"), (1, 8, 32, 2, "elu"), (3, 24, 96, 2, None), (2, 26, 64, 2, "leaky"),
-                 (4, 160, 160, 2, "leaky")]
+RDIRECT_CASES = [  # B, H, W, Cin, Cout, k, stride, act, residual
+    (2, 16, 32, 64, 128, 3, 2, "leaky", False), (1, 8, 32, 64, 128, 3, 2, "elu", False), (3, 24, 96, 64, 128, 3, 2, None, False),
+    (2, 26, 64, 64, 128, 3, 2, "leaky", False), (4, 160, 160, 64, 128, 3, 2, "leaky", False),
+    # pointwise forms (stages 1-2 in training: forward without, backward-data with the in-place residual sum)
+    (2, 12, 32, 64, 32, 1, 1, "leaky", False), (1, 7, 48, 32, 64, 1, 1, None, True), (3, 9, 16, 128, 64, 1, 1, "elu", False),
+    (2, 10, 64, 64, 128, 1, 1, None, True), (8, 160, 160, 64, 32, 1, 1, "leaky", False), (8, 160, 160, 32, 64, 1, 1, None, True)]
 
 
 @pytest.mark.parametrize("case", RDIRECT_CASES, ids=str)
-def test_conv_64_to_128_weights_resident_kernel(cuda, case, monkeypatch):
-    """od_conv_rdirect (conv_rdirect.hip): 3x3, 64 -> 128 channels, all nine weight taps in LDS, the pixel operand read
-    straight from global memory -- what od_conv2d_fwd picks for `b.down2` (stride 2) on large maps (the size threshold is
-    lifted here so that small maps reach it too).  vs the f64 oracle like every other config, and vs the table kernel the
-    library would otherwise take (same inputs: equal to 1 f16 ulp + accumulation-order noise)."""
+def test_conv_weights_resident_kernels(cuda, case, monkeypatch):
+    """od_conv_rdirect (conv_rdirect.hip): all weights in LDS, the pixel operand read straight from global memory -- what
+    od_conv2d_fwd picks for `b.down2` (3x3 stride 2, 64 -> 128) and for the pointwise layers of stages 1-2 on large maps (the
+    size threshold is lifted here so that small maps reach it too).  vs the table kernel the library would otherwise take
+    (same inputs: equal to 1 f16 ulp + accumulation-order noise) and, on the small cases, vs the f64 oracle."""
     from object_detector_amd import ops
     monkeypatch.setenv("OD_CONV_RDIRECT_MIN_PIXELS", "0")
-    B, H, W, stride, act = case
-    Cin, Cout, k = 64, 128, 3
+    B, H, W, Cin, Cout, k, stride, act, with_res = case
     rng = np.random.default_rng(hash(case) & 0xFFFF)
     x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float16)
     w = (rng.normal(0, 1, (Cout, k, k, Cin)) * np.sqrt(2.0 / (k * k * Cin))).astype(np.float16)
     scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
     bias = rng.normal(0, 0.1, Cout).astype(np.float32)
     alpha = 0.1 if act == "leaky" else 1.0
+    Ho, Wo = H // stride, W // stride
+    res = rng.normal(0, 1, (B, Ho, Wo, Cout)).astype(np.float16) if with_res else None
     xt = torch.from_numpy(x).to(cuda)
-    out = ops.conv2d(xt, w.astype(np.float32), scale, bias, stride=stride, act=act, alpha=alpha, tile_cfg=-1)
-    gen = ops.conv2d(xt, w.astype(np.float32), scale, bias, stride=stride, act=act, alpha=alpha, tile_cfg=2)
+    rt = torch.from_numpy(res).to(cuda) if with_res else None
+    kw = dict(stride=stride, act=act, alpha=alpha, res=rt, res_mode="same" if with_res else "none")
+    out = ops.conv2d(xt, w.astype(np.float32), scale, bias, tile_cfg=-1, **kw)
+    gen = ops.conv2d(xt, w.astype(np.float32), scale, bias, tile_cfg=2, **kw)
     torch.cuda.synchronize()
     got, g = out.cpu().numpy().astype(np.float64), gen.cpu().numpy().astype(np.float64)
     tolg = 1e-3 * max(1.0, np.abs(g).max()) + 2.0 ** -10 * np.abs(g)
     assert (np.abs(got - g) <= tolg).all(), f"vs table kernel: max {np.abs(got - g).max()}"
     if B * H * W <= 20000:  # the f64 oracle on the CPU
-        ref = _ref(x.astype(np.float32), w.astype(np.float32), scale, bias, stride, act, alpha)
+        ref = _ref(x.astype(np.float32), w.astype(np.float32), scale, bias, stride, act, alpha,
+                   None if res is None else res.astype(np.float32))
         err = np.abs(got - ref)
         tol = 1e-3 * max(1.0, np.abs(ref).max()) + 2.0 ** -10 * np.abs(ref)
         assert got.shape == ref.shape and (err <= tol).all(), f"max err {err.max()}"
