@@ -643,7 +643,7 @@ static int od_conv2d_fwd_main(od_ctx* ctx, const od_conv_desc* d, hipStream_t st
     }
     if (allow) return od_tconv_small_launch(ctx, d, stream, kernel_name, dry_run);
   }
-  if (!tconv && d->tile_cfg < 0 && od_conv_rdirect_supported(d)) {
+  if (d->tile_cfg < 0 && od_conv_rdirect_supported(d)) {  // (also the transposed form of b.down2's backward-data)
     static int allow = -1;
     if (allow < 0) {
       const char* e = getenv("OD_CONV_RDIRECT");  // 0 = the table kernels (A/B timing)

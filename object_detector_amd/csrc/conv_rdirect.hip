@@ -181,6 +181,134 @@ __global__ __launch_bounds__(512, 2) void od_conv_rdirect(RdKP p) {
   }
 }
 
+// Transposed form: backward-data of `b.down2` (dZ [B, Hs, Ws, 128] -> dX [B, 2Hs, 2Ws, 64]; the packed backward weights, 147 KiB,
+// resident).  An item = 16 dZ pixels of one row; the lane's four source pixels (i + {0,1}, j + {0,1}) x 4 k steps are 16
+// direct loads; the four output parity classes take 1 / 2 / 2 / 4 of the nine taps (conv_tconv.hip has the derivation):
+// 144 MFMAs, eight 16-byte stores per lane.  The generic transposed path runs this layer in 122 us (157 MB of traffic).
+template <int KC, int NC>
+__global__ __launch_bounds__(512, 2) void od_tconv_rdirect(RdKP p) {
+  constexpr int ROWB = KC * 2, CH = ROWB / 16, KH = KC / 32, NF = NC / 16, WROWS = 9 * NC;
+  extern __shared__ __attribute__((aligned(16))) char wlds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  {
+    constexpr int LPR = CH, RPP = 64 / LPR, PIECES = WROWS / RPP;
+    for (int q = wave; q < PIECES; q += 8) {
+      const int r = q * RPP + lane / LPR;
+      const int tap = r / NC, n = r - tap * NC;
+      const int lc = rd_swz<CH>(lane % LPR, r);
+      glds16(p.w + ((long long)n * p.Kstride + tap * KC + lc * 8), wlds + q * 1024);
+    }
+  }
+  // here p.H / p.W are the dZ map (Hs, Ws), p.Ho / p.Wo the output map (2Hs, 2Ws); an item = (dZ row, 16-pixel segment)
+  auto load_item = [&](int item, f16x8 (&xs)[4][KH]) {
+    const int row = item / p.segs_per_row, j0 = (item - row * p.segs_per_row) * 16;
+    const int b = row / p.H, i = row - b * p.H;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int u = i + dy, v = j0 + l15 + dx;
+        const bool ok = u < p.H && v < p.W;
+        const f16* src = p.x + (((long long)(b * p.H + u) * p.W + v) * KC + lq * 8);
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+          f16x8 val = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (ok) val = *(const f16x8*)(src + kh * 32);
+          xs[dy * 2 + dx][kh] = val;
+        }
+      }
+  };
+  const int n8 = (lq & 1) * 16 + (lq >> 1) * 8;
+  const int gw = blockIdx.x * 8 + wave, nw = gridDim.x * 8;
+  f16x8 xa[4][KH], xb[4][KH];
+  int item = gw;
+  if (item < p.nitems) load_item(item, xa);
+  float* const sb = (float*)(wlds + WROWS * ROWB);
+  if (tid < NC) {
+    sb[tid] = p.scale[tid];
+    sb[NC + tid] = p.bias[tid];
+  }
+  wait_vmcnt<0>();
+  __syncthreads();
+  int fwk[KH];
+#pragma unroll
+  for (int kh = 0; kh < KH; ++kh) fwk[kh] = l15 * ROWB + rd_swz<CH>(kh * 4 + lq, l15) * 16;
+
+  auto compute_store = [&](int it, f16x8 (&xs)[4][KH]) {
+    const int row = it / p.segs_per_row, j0 = (it - row * p.segs_per_row) * 16;
+    const int b = row / p.H, i = row - b * p.H;
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) {  // one parity class at a time: 16 accumulator registers live
+      const int py = cls >> 1, px = cls & 1;
+      f32x4 acc[NF];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          if ((ty == 1 ? 0 : 1) != py || (tx == 1 ? 0 : 1) != px) continue;
+          const int src = (ty == 2 ? 2 : 0) + (tx == 2 ? 1 : 0), tap = ty * 3 + tx;
+#pragma unroll
+          for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+              const f16x8 wv = *(const f16x8*)(wlds + (tap * NC + f * 16) * ROWB + fwk[kh]);
+              acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xs[src][kh], acc[f], 0, 0, 0);
+            }
+        }
+      od_mfma_results_ready();
+      const long long ooff = (((long long)b * p.Ho + 2 * i + py) * p.Wo + 2 * (j0 + l15) + px) * NC + n8;
+#pragma unroll
+      for (int s = 0; s < NC / 32; ++s) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = acc[2 * s][e], bq = acc[2 * s + 1][e];
+          od_permlane16_swap(a, bq);
+          o[e] = a;
+          o[4 + e] = bq;
+        }
+        const f32x4 s0 = *(const f32x4*)(sb + s * 32 + n8), s1 = *(const f32x4*)(sb + s * 32 + n8 + 4);
+        const f32x4 b0 = *(const f32x4*)(sb + NC + s * 32 + n8), b1 = *(const f32x4*)(sb + NC + s * 32 + n8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = o[e] * s0[e] + b0[e];
+          o[4 + e] = o[4 + e] * s1[e] + b1[e];
+        }
+        if (p.act == OD_ACT_LEAKY) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = od_leaky(o[e], p.alpha);
+        } else if (p.act == OD_ACT_ELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = o[e] > 0.f ? o[e] : p.alpha * od_expm1_fast(o[e]);
+        }
+        if (p.res) {
+          const f16x8 rv = *(const f16x8*)(p.res + ooff + s * 32);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += (float)rv[e];
+        }
+        f16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (f16)o[e];
+        *(f16x8*)(p.out + ooff + s * 32) = h;
+      }
+    }
+  };
+  while (item < p.nitems) {
+    const int n1 = item + nw;
+    if (n1 < p.nitems) load_item(n1, xb);
+    compute_store(item, xa);
+    if (n1 >= p.nitems) break;
+    const int n2 = n1 + nw;
+    if (n2 < p.nitems) load_item(n2, xa);
+    compute_store(n1, xb);
+    item = n2;
+  }
+}
+
 struct RdEntry {
   int kc, nc, stride, ks;
   const void* fn;
@@ -195,7 +323,10 @@ const RdEntry g_rd[] = {
     // (stride 1 -- b.s2.*.b in training -- is instantiable but not offered: there every pixel is loaded nine times and the
     //  kernel is L1-bound, 60-63 us against 58-59 us on the table kernel; stride 2 loads a pixel 2.25 times: 76 -> 54 us)
 };
+const RdEntry g_rdt = {128, 64, 2, 3, (const void*)&od_tconv_rdirect<128, 64>, "od_tconv_rdirect<128, 64>",
+                       (size_t)9 * 64 * 256 + 1024};
 const RdEntry* rd_find(const od_conv_desc* d) {
+  if (d->transposed) return (d->Cin == 128 && d->Cout == 64 && d->ksize == 3 && d->stride == 2) ? &g_rdt : nullptr;
   for (const RdEntry& e : g_rd)
     if (e.kc == d->Cin && e.nc == d->Cout && e.stride == d->stride && e.ks == d->ksize) return &e;
   return nullptr;
@@ -204,15 +335,16 @@ const RdEntry* rd_find(const od_conv_desc* d) {
 }  // namespace
 
 bool od_conv_rdirect_supported(const od_conv_desc* d) {
-  if (d->transposed || (d->res_mode != OD_RES_NONE && d->res_mode != OD_RES_SAME) || d->out_dtype != OD_DT_F16 ||
-      d->out_batch_stride != 0 || d->out_pix_stride != 0 || d->bn_partials || d->w2 || d->H % d->stride || d->W % d->stride)
+  if ((d->res_mode != OD_RES_NONE && d->res_mode != OD_RES_SAME) || d->out_dtype != OD_DT_F16 || d->out_batch_stride != 0 ||
+      d->out_pix_stride != 0 || d->bn_partials || d->w2)
     return false;
-  const int Wo = d->W / d->stride;
+  if (!d->transposed && (d->H % d->stride || d->W % d->stride)) return false;
+  const int Wo = d->transposed ? d->W : d->W / d->stride;  // (transposed: items are 16-pixel segments of the dZ rows)
   if (rd_find(d) == nullptr || Wo % 16 != 0 || (long long)d->B * d->H * d->W * d->Cin >= (1LL << 31)) return false;
   // large maps only: the 147 KiB of weights are loaded once per workgroup (OD_CONV_RDIRECT_MIN_PIXELS overrides: tests)
   long long min_px = d->ksize == 3 ? (1 << 18) : (1 << 16);  // (the pointwise forms load at most 16 KiB of weights)
   if (const char* e = getenv("OD_CONV_RDIRECT_MIN_PIXELS")) min_px = atoll(e);
-  return (long long)d->B * d->H * d->W >= min_px;
+  return (long long)d->B * d->H * d->W * (d->transposed ? 4 : 1) >= min_px;  // (transposed: the output map is the large one)
 }
 
 int od_conv_rdirect_launch(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, const char** kernel_name, bool dry_run) {
@@ -229,13 +361,13 @@ int od_conv_rdirect_launch(od_ctx* ctx, const od_conv_desc* d, hipStream_t strea
   p.res = d->res_mode == OD_RES_SAME ? (const f16*)d->res : nullptr;
   p.H = d->H;
   p.W = d->W;
-  p.Ho = d->H / d->stride;
-  p.Wo = d->W / d->stride;
+  p.Ho = d->transposed ? 2 * d->H : d->H / d->stride;
+  p.Wo = d->transposed ? 2 * d->W : d->W / d->stride;
   p.Kstride = od_round_up(d->ksize * d->ksize * d->Cin, 64);
   p.act = d->act;
   p.alpha = d->alpha;
-  p.segs_per_row = p.Wo / 16;
-  p.nitems = d->B * p.Ho * p.segs_per_row;
+  p.segs_per_row = (d->transposed ? d->W : p.Wo) / 16;
+  p.nitems = d->B * (d->transposed ? d->H : p.Ho) * p.segs_per_row;
   const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
   int grid = d->ksize == 1 ? 2 * cus : cus;  // (the 3x3 form holds 147 KiB of LDS: one workgroup per CU)
   if (grid * 8 > p.nitems) grid = od_ceil_div(p.nitems, 8);

@@ -401,3 +401,30 @@ def test_first_layer_weight_gradient(cuda, case):
     assert np.array_equal(outs[0], outs[1])
     got = outs[0].astype(np.float64) - base
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("case", [(2, 8, 16), (1, 5, 48), (3, 20, 32), (32, 80, 80)], ids=str)
+def test_second_downsample_backward_data_weights_resident_kernel(cuda, case, monkeypatch):
+    """od_tconv_rdirect<128, 64> (conv_rdirect.hip; what od_conv2d_fwd(transposed=1) runs for dZ 128 -> dX 64 channels on large
+    maps: `b.down2` backward-data) against the generic transposed path, with and without the in-place accumulation into an
+    existing gradient: equal up to the f32 accumulation order; two runs are bit-identical."""
+    from object_detector_amd import train_ops as T
+    monkeypatch.setenv("OD_CONV_RDIRECT_MIN_PIXELS", "0")
+    B, Hs, Ws = case
+    rng = np.random.default_rng(B * 1000 + Hs + 7)
+    dz = torch.from_numpy(rng.normal(0, 1, (B, Hs, Ws, 128)).astype(np.float16)).to(cuda)
+    wm = torch.from_numpy((rng.normal(0, 1, (128, 576)) * np.sqrt(2.0 / 576)).astype(np.float32)).to(cuda)
+    _wf, wb = T.pack_weights(wm, 128, 64, 3)
+    ones, zeros = torch.ones(wb.shape[0], device=cuda), torch.zeros(wb.shape[0], device=cuda)
+    acc = torch.from_numpy(rng.normal(0, 1, (B, 2 * Hs, 2 * Ws, 64)).astype(np.float16)).to(cuda)
+    for res in (None, acc):
+        kw = dict(stride=2, transposed=True, res=res, res_mode="same" if res is not None else "none")
+        a = T.conv_packed(dz, wb, ones, zeros, 128, 64, 3, **kw)
+        b = T.conv_packed(dz, wb, ones, zeros, 128, 64, 3, **kw)
+        g = T.conv_packed(dz, wb, ones, zeros, 128, 64, 3, tile_cfg=1, **kw)
+        torch.cuda.synchronize()
+        assert a.shape == (B, 2 * Hs, 2 * Ws, 64) and torch.equal(a, b)
+        af, gf = a.float(), g.float()
+        tol = 1e-3 * max(1.0, float(gf.abs().max())) + 2.0 ** -10 * gf.abs()
+        bad = (af - gf).abs() > tol
+        assert not bool(bad.any()), f"{int(bad.sum())} elements differ, max {float((af - gf).abs().max())}"
