@@ -522,13 +522,20 @@ static bool wgrad_use_w8(int cus, int M, int Cout, int Ktot) {
   if (force == 1) return true;
   const long long tiles = (long long)od_ceil_div(Cout, W8_TILE) * od_ceil_div(Ktot, W8_TILE);
   const double eff = (double)Cout * Ktot / (double)(tiles * W8_TILE * W8_TILE);
-  const int split = wgrad_w8_split(cus, od_ceil_div(M, KC), Cout, Ktot, nullptr);
-  static int min_wgs = -1;
+  int cps = 0;
+  const int split = wgrad_w8_split(cus, od_ceil_div(M, KC), Cout, Ktot, &cps);
+  static int min_wgs = -1, min_cps = -1;
   if (min_wgs < 0) {
     const char* e = getenv("OD_WGRAD_W8_MIN");
     min_wgs = e ? atoi(e) : 160;
+    // pixel chunks per workgroup below which the 128 x 128 kernel is taken.  Standalone the 256-wide kernel wins from ~24
+    // chunks; INSIDE the two-stream step it holds a whole CU (128 KiB of LDS, 256 VGPRs x 8 waves) while the other stream's
+    // kernels wait for a slot, and only pays with long pixel runs: 32 x 320^2 (31 chunks per workgroup on stage 3) 10.80 ->
+    // 10.65 ms without it, 16 x 640^2 (63) 17.5 -> 18.0 ms without it; 60 keeps both (sweep: profiles/r02/wgrad_w8_cps_sweep.txt)
+    const char* c = getenv("OD_WGRAD_W8_CPS");
+    min_cps = c ? atoi(c) : 60;
   }
-  return eff >= 0.74 && tiles * split >= min_wgs;
+  return eff >= 0.74 && tiles * split >= min_wgs && cps >= min_cps;
 }
 
 // the thin kernel's shapes (slab output only): 3x3, 32 -> 64 channels, output rows that are whole 32-pixel chunks

@@ -194,7 +194,7 @@ def test_bn_fold_bit_exact_vs_numpy(cuda):
                                   (5, 40, 128, 32, 64, 3, 2), (16, 160, 160, 32, 64, 3, 1)], ids=str)
 def test_weight_gradient_slab_path_many_splits(cuda, case):
     """The form the trainer uses: per-split f32 slabs (plain stores) + fixed-order reduce, at sizes where the pixel range is
-    split over many workgroups (33 splits of the 256-wide kernel on the first case).  vs torch conv2d weight gradient in
+    split over many workgroups (both kernels: the 256-wide one needs >= 60 chunks per workgroup, e.g. the 16 x 160 x 160 case).  vs torch conv2d weight gradient in
     f64; two runs are bit-identical (no atomics anywhere)."""
     import ctypes as C
     from object_detector_amd import _lib
