@@ -171,3 +171,42 @@ def test_predict_from_files_with_decode_pool(cuda, tmp_path, monkeypatch):
         assert np.array_equal(a.flat_indices, b.flat_indices) and np.array_equal(a.bboxes, b.bboxes)
         assert np.array_equal(a.flat_indices, c.flat_indices)
         assert np.array_equal(a.flat_indices, d.flat_indices) and np.array_equal(a.bboxes, d.bboxes)
+
+
+@pytest.mark.parametrize("case", [(8, 352, 480, "1"), (20, 256, 256, "0"), (12, 512, 384, "1")], ids=str)
+def test_shape_driven_kernel_selection_at_odd_sizes(cuda, case, monkeypatch):
+    """Which kernel a layer takes depends on its map size (the streaming / weights-resident kernels and the 1x1 layers that
+    ride in their producer's launch switch on and off with it): sizes and batch sizes no other test uses, the throughput and
+    the latency plan, fused blocks and layer by layer -- logits by the size-independent criteria of oracle/compare.py, kept
+    indices bit-exact against the oracle NMS fed the device's conf / boxes."""
+    from object_detector_amd.detector import ObjectDetector
+    from oracle.compare import assert_logits, logit_stats
+    B, H, W, fuse = case
+    monkeypatch.setenv("OD_FUSE_BLOCKS", fuse)
+    x = np.random.default_rng(B * 1000 + H).integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    xt = torch.from_numpy(x).to(cuda)
+    ref = ref32 = None
+    for nin in (3, 1):
+        od = ObjectDetector.synthetic(B, (H, W), seed=2, device=cuda, use_multi_gpu=False, n_inflight=nin)
+        if ref is None:
+            ref = onet.Runner(od.params, storage="f16").forward(x)
+            ref32 = onet.Runner(od.params, storage="f32").forward(x)
+        if nin == 3:
+            t = od.submit(xt, conf_threshold=0.01)
+            keep, cnt = od.collect(t)
+            p = od._pipes[t]
+            pred, conf, boxes = p.net.pred.cpu().numpy(), p.post.conf.cpu().numpy(), p.post.boxes.cpu().numpy()
+            names = sorted(set(p.net.time_ops()[1]))
+        else:
+            keep, cnt = od.predict_batch_device(xt, conf_threshold=0.01)
+            torch.cuda.synchronize()
+            pred, conf, boxes = od.net.pred.cpu().numpy(), od.post.conf.cpu().numpy(), od.post.boxes.cpu().numpy()
+            names = sorted(set(od.net.time_ops()[1]))
+        assert_logits(logit_stats(pred, ref, ref32), f"{B}x{H}x{W} fuse={fuse} inflight {nin}")
+        keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+        for b in range(B):
+            r, *_ = onms.detect_image(conf[b], boxes[b], K=1024, conf_threshold=0.01, iou_threshold=0.45, max_det=200)
+            assert cnt[b] == len(r) and (keep[b, :len(r)] == r).all(), f"image {b}: kept indices differ"
+        print(f"{case} inflight {nin}:", [n for n in names if any(k in n for k in ("rdirect", "stream3", "true>", "stem", "bneck"))])
+        del od
+        torch.cuda.empty_cache()
