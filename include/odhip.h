@@ -337,6 +337,10 @@ int od_sgd_step_multi(od_ctx* ctx, float* w, float* m, const float* g, const od_
 /* flag[0] (DEVICE int32) = 1 when any of g[0..n) is Inf / NaN, else 0.  Run it on the flat gradient buffer AFTER the
  * all-reduce: a non-finite value on one rank reaches every rank through the sum, so all ranks skip the same step. */
 int od_grad_nonfinite(od_ctx* ctx, const float* g, long long n, int32_t* flag, void* stream);
+/* dst[0..n) = src[0..n) when *flag (DEVICE int32) != 0, untouched otherwise.  The trainer keeps a copy of the BatchNorm
+ * running statistics taken before forward and restores it with this call when od_grad_nonfinite flagged the step: the
+ * skipped step's forward has already folded its (possibly overflowed) batch statistics into them. */
+int od_copy_if_nonzero(od_ctx* ctx, float* dst, const float* src, long long n, const int32_t* flag, void* stream);
 /* f32 <-> bf16 (round to nearest even) for the bf16 gradient payload of od_allreduce(OD_DT_BF16) */
 int od_cast_f32_bf16(od_ctx* ctx, const float* src, void* dst, long long n, void* stream);
 int od_cast_bf16_f32(od_ctx* ctx, const void* src, float* dst, long long n, void* stream);

@@ -726,6 +726,21 @@ extern "C" int od_grad_nonfinite(od_ctx* ctx, const float* g, long long n, int32
   return OD_OK;
 }
 
+// dst[0..n) = src[0..n) when *flag != 0 (no-op otherwise): the trainer restores the BatchNorm running statistics of a
+// step whose update was skipped (the forward pass that overflowed has already folded its batch statistics into them)
+__global__ __launch_bounds__(256) void od_copy_if_k(float* __restrict__ dst, const float* __restrict__ src, long long n,
+                                                    const int32_t* __restrict__ flag) {
+  if (*flag == 0) return;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+
+extern "C" int od_copy_if_nonzero(od_ctx* ctx, float* dst, const float* src, long long n, const int32_t* flag, void* stream) {
+  OD_REQUIRE(ctx && dst && src && flag && n > 0, "od_copy_if_nonzero: bad argument");
+  hipLaunchKernelGGL(od_copy_if_k, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dst, src, n, flag);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
 // f32 <-> bf16 (round to nearest even; Inf / NaN preserved) for the bf16 gradient all-reduce payload (BASELINE.json
 // configs[4]; SURVEY.md §0.1 "bf16 for the all-reduce payload")
 __global__ __launch_bounds__(256) void od_f32_to_bf16_k(const float* __restrict__ src, uint16_t* __restrict__ dst, long long n) {

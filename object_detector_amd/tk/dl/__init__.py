@@ -29,17 +29,27 @@ def session(device=None):
     import torch
     rank, local_rank, world = dist_env()
     created = False
-    ndev = torch.cuda.device_count()  # does not initialise the GPU runtime
+    ndev = torch.cuda.device_count()  # only counts devices; this process has made no other GPU call yet
+    # ONE device decision for both the process group and set_device: the caller's, else this rank's GPU
+    dev = None
+    if ndev > 0:
+        dev = torch.device(device) if device is not None else torch.device(f"cuda:{local_rank % ndev}")
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device(f"cuda:{local_rank % ndev}")
     if world > 1 and torch.distributed.is_available() and not torch.distributed.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC; must be set before the runtime comes up
         backend = os.environ.get("OD_DIST_BACKEND") or os.environ.get("OD_BENCH_BACKEND") or ("nccl" if ndev > 0 else "gloo")
         if backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank % ndev}"))
+            if dev is None or dev.type != "cuda":
+                from ..._lib import OdError
+                raise OdError("backend nccl (RCCL) was requested but this process sees no GPU; set OD_DIST_BACKEND=gloo "
+                              "for a CPU rehearsal")
+            torch.distributed.init_process_group("nccl", device_id=dev)
         else:
             torch.distributed.init_process_group(backend)
         created = True
-    if ndev > 0 and torch.cuda.is_available():
-        torch.cuda.set_device((local_rank % ndev) if device is None else device)
+    if dev is not None and dev.type == "cuda" and torch.cuda.is_available():
+        torch.cuda.set_device(dev)
     try:
         yield
     finally:

@@ -24,12 +24,14 @@ from .pb import PriorBoxes
 BN_MOMENTUM = 0.99  # Keras default
 
 
-def lr_multiplier(name: str) -> float:
-    """docs/MODEL.md:84-90"""
-    if name.startswith("b."):
-        return 0.01
-    if name.startswith("h."):
-        return 1.0 / 3.0
+LR_MULTIPLIERS = {"b.": 0.01, "h.": 1.0 / 3.0}  # docs/MODEL.md:84-90: base network x 1/100, shared layers x 1/(times shared)
+
+
+def lr_multiplier(name: str, table=None) -> float:
+    """docs/MODEL.md:84-90.  `table`: {layer-name prefix: multiplier}, first matching prefix wins, no match = 1."""
+    for prefix, m in (LR_MULTIPLIERS if table is None else table).items():
+        if name.startswith(prefix):
+            return float(m)
     return 1.0
 
 
@@ -41,7 +43,8 @@ class _Node:
 class Trainer:
     def __init__(self, params, batch_size, input_size=(320, 320), device="cuda:0", lr=1e-3, momentum=0.9,
                  weight_decay=0.0, loss_scale=1024.0, box_mode="smooth_l1", backbone_act=("leaky", 0.1),
-                 head_act=("elu", 1.0), comm=None, world_size=1, grad_payload=None, dynamic_loss_scale=True):
+                 head_act=("elu", 1.0), comm=None, world_size=1, grad_payload=None, dynamic_loss_scale=True,
+                 lr_multipliers=None):
         self.ctx = Context.get(device)
         self.lib = self.ctx.lib
         self.device = torch.device(device)
@@ -51,6 +54,9 @@ class Trainer:
         self.C = self.num_classes + 6
         self.lr, self.momentum, self.weight_decay = float(lr), float(momentum), float(weight_decay)
         self.loss_scale, self.box_mode = float(loss_scale), box_mode
+        # per-layer learning-rate multipliers (docs/MODEL.md:84-90 by default: the reference fine-tunes a PRE-TRAINED base
+        # network at 1/100; a from-scratch run passes {"h.": 1/3} to train the base network at the full rate)
+        self.lr_multipliers = dict(LR_MULTIPLIERS if lr_multipliers is None else lr_multipliers)
         self.comm, self.world = comm, int(world_size)
         # gradient all-reduce payload: "f32" (exact sum) or "bf16" (BASELINE.json configs[4]: half the xGMI bytes; each rank's
         # f32 gradients are rounded to bf16, summed by RCCL in bf16, widened back to f32 before the optimizer)
@@ -86,10 +92,23 @@ class Trainer:
         self.params = torch.from_numpy(host).to(dev)
         self.grads = torch.zeros_like(self.params)
         self.mom = torch.zeros_like(self.params)
-        self.run_mean = {n: torch.from_numpy(np.asarray(params[n + ".mean"], np.float32)).to(dev)
-                         for n, s in self.specs.items() if s[5]}
-        self.run_var = {n: torch.from_numpy(np.asarray(params[n + ".var"], np.float32)).to(dev)
-                        for n, s in self.specs.items() if s[5]}
+        # BatchNorm running statistics: ONE flat buffer (views per layer), so that a skipped step can put back the copy taken
+        # before its forward pass with one launch (od_copy_if_nonzero)
+        roff, rviews = 0, {}
+        for n, sp in self.specs.items():
+            if sp[5]:
+                rviews[n] = roff
+                roff += 2 * ((sp[2] + 3) // 4 * 4)
+        rhost = np.zeros(max(roff, 4), np.float32)
+        for n, o in rviews.items():
+            c = self.specs[n][2]
+            cp = (c + 3) // 4 * 4
+            rhost[o:o + c] = np.asarray(params[n + ".mean"], np.float32)
+            rhost[o + cp:o + cp + c] = np.asarray(params[n + ".var"], np.float32)
+        self.run_stats = torch.from_numpy(rhost).to(dev)
+        self.run_stats_saved = torch.empty_like(self.run_stats)
+        self.run_mean = {n: self.run_stats[o:o + self.specs[n][2]] for n, o in rviews.items()}
+        self.run_var = {n: self.run_stats[o + (self.specs[n][2] + 3) // 4 * 4:][:self.specs[n][2]] for n, o in rviews.items()}
         maxpad = 2048
         self.ones = torch.ones(maxpad, dtype=torch.float32, device=dev)
         self.zeros = torch.zeros(maxpad, dtype=torch.float32, device=dev)
@@ -133,8 +152,7 @@ class Trainer:
         self.payload_buf = (torch.empty(self.n_flat, dtype=torch.bfloat16, device=dev) if self.grad_payload == "bf16"
                             else None)
         self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._nonfinite_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        self._nonfinite_ev = None
+        self._flag_queue, self._flag_pool = [], []  # (event, pinned host flag) of steps whose flag copy is still in flight
         self._buckets = self._make_buckets(int(self.bucket_mb * (1 << 20) / 4)) if self.cstream is not None else []
         self._next_bucket = 0
         mxc = max(self.lib.od_bn_workspace_bytes(self.B * (n.H // n.stride) * (n.W // n.stride), n.Cout) + 2 * n.Cout * 4
@@ -298,6 +316,7 @@ class Trainer:
         self.tensors["img"].copy_(x_u8, non_blocking=True)
         lib, h = self.lib, self.ctx.handle
         s = _stream_ptr()
+        self.run_stats_saved.copy_(self.run_stats, non_blocking=True)  # put back by sgd() when the step is skipped
         for n in self.nodes:
             x = self.tensors[n.x]
             if n.first:
@@ -516,13 +535,13 @@ class Trainer:
         # after the all-reduce, so every rank sees the same flag: Inf / NaN anywhere -> this step's update is skipped
         _lib.check(self.lib.od_grad_nonfinite(self.ctx.handle, self.grads.data_ptr(), self.n_flat, self.nonfinite.data_ptr(),
                                               _stream_ptr()), "od_grad_nonfinite")
-        key = (self.lr, self.weight_decay)
+        key = (self.lr, self.weight_decay, tuple(sorted(self.lr_multipliers.items())))
         if getattr(self, "_sgd_key", None) != key:
             segs = []
             for (name, kind), (o, n) in self.seg.items():
                 sg = _lib.SgdSeg()
                 sg.offset, sg.count = o, n
-                sg.lr = self.lr * lr_multiplier(name)
+                sg.lr = self.lr * lr_multiplier(name, self.lr_multipliers)
                 sg.weight_decay = self.weight_decay if kind == "w" else 0.0
                 segs.append(sg)
             self._sgd_table, self._sgd_n, self._sgd_key = self._device_table(segs), len(segs), key
@@ -530,33 +549,48 @@ class Trainer:
                                               self.grads.data_ptr(), self._sgd_table.data_ptr(), self._sgd_n,
                                               self.momentum, inv, self.nonfinite.data_ptr(), _stream_ptr()),
                    "od_sgd_step_multi")
+        # a skipped step also takes back what its forward pass did to the BatchNorm running statistics: when the Inf / NaN
+        # came from an f16 overflow in z (not from a loss-scaled dz) the batch statistics folded into them are non-finite
+        _lib.check(self.lib.od_copy_if_nonzero(self.ctx.handle, self.run_stats.data_ptr(), self.run_stats_saved.data_ptr(),
+                                               self.run_stats.numel(), self.nonfinite.data_ptr(), _stream_ptr()),
+                   "od_copy_if_nonzero")
         self._repack()  # (a skipped step re-packs unchanged masters: harmless, and keeps the launch sequence fixed)
-        self._nonfinite_host.copy_(self.nonfinite, non_blocking=True)
-        self._nonfinite_ev = torch.cuda.Event()
-        self._nonfinite_ev.record()
+        host = self._flag_pool.pop() if self._flag_pool else torch.zeros(1, dtype=torch.int32).pin_memory()
+        host.copy_(self.nonfinite, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._flag_queue.append((ev, host))
 
-    def _poll_nonfinite(self):
-        """The previous step's flag (its copy finished long ago: no stall).  A skipped step halves the loss scale; a long
-        clean run doubles it again.  BatchNorm running statistics were already updated by the skipped step's forward --
-        they are a moving average of finite activations and stay valid."""
-        if self._nonfinite_ev is None:
-            return
-        self._nonfinite_ev.synchronize()
-        self._nonfinite_ev = None
-        if int(self._nonfinite_host[0]) != 0:
-            self.skipped_steps += 1
-            self._good_steps = 0
-            if self.dynamic_loss_scale:
-                self.loss_scale = max(1.0, self.loss_scale * 0.5)
-        else:
-            self._good_steps += 1
-            if self.dynamic_loss_scale and self._good_steps >= self.loss_scale_growth_interval:
-                self.loss_scale, self._good_steps = min(self.loss_scale * 2.0, 65536.0), 0
+    def _poll_nonfinite(self, wait=False):
+        """Consume the flags of earlier steps whose device->host copy HAS completed (event.query(): the host never waits
+        for the previous step here, so encode_batch and the first launches of this step overlap its tail; the loss scale
+        reacts one or two steps late).  A skipped step halves the loss scale; a long clean run doubles it again.
+        wait=True drains the queue (end of fit(), tests)."""
+        while self._flag_queue:
+            ev, host = self._flag_queue[0]
+            if wait:
+                ev.synchronize()
+            elif not ev.query():
+                break
+            self._flag_queue.pop(0)
+            bad = int(host[0]) != 0
+            self._flag_pool.append(host)
+            if bad:
+                self.skipped_steps += 1
+                self._good_steps = 0
+                if self.dynamic_loss_scale:
+                    self.loss_scale = max(1.0, self.loss_scale * 0.5)
+            else:
+                self._good_steps += 1
+                if self.dynamic_loss_scale and self._good_steps >= self.loss_scale_growth_interval:
+                    self.loss_scale, self._good_steps = min(self.loss_scale * 2.0, 65536.0), 0
 
     def sgd_per_tensor(self):
+        """Per-tensor form of sgd() (kept for the equality test of the multi-tensor kernels).  UNGUARDED: no non-finite
+        check, no loss-scale update, no restore of the running statistics -- training loops use sgd()."""
         inv = dp_effective_scale(self.loss_scale, self.world)  # grads are averaged over ranks
         for (name, kind), (o, n) in self.seg.items():
-            lr = self.lr * lr_multiplier(name)
+            lr = self.lr * lr_multiplier(name, self.lr_multipliers)
             wd = self.weight_decay if kind == "w" else 0.0
             _lib.check(self.lib.od_sgd_step(self.ctx.handle, self.params.data_ptr() + 4 * o, self.mom.data_ptr() + 4 * o,
                                             self.grads.data_ptr() + 4 * o, n, lr, self.momentum, wd, inv, _stream_ptr()),
@@ -574,6 +608,28 @@ class Trainer:
         self.allreduce()
         self.sgd()
         return self.losses
+
+    def fit(self, batches, steps, lr_schedule=None, log_every=0, log=print):
+        """Run `steps` training steps from an iterator of (x_u8 [B,H,W,3] device tensor, y_target [B,P,C] device tensor or
+        list of annotations) -- what od_gen.Generator(on_device=True).flow(...) yields (the reference's unseen `fit`:
+        generator -> encode_truth -> losses, check_assign.py:21-22).  lr_schedule(step) -> learning rate.  Returns the
+        per-step losses [steps, 4] (objectness, class, box, total) as a numpy array; losses stay on the device until the
+        end, so the loop never synchronises."""
+        hist = torch.zeros((steps, 4), dtype=torch.float32, device=self.device)
+        for i, (xb, yb) in zip(range(steps), batches):
+            if lr_schedule is not None:
+                self.lr = float(lr_schedule(i))
+            if isinstance(yb, torch.Tensor):
+                self.step(xb, y_target=yb)
+            else:
+                self.step(xb, annotations=yb)
+            hist[i].copy_(self.losses)
+            if log_every and (i + 1) % log_every == 0:
+                l = hist[i].cpu().numpy()
+                log(f"step {i + 1}/{steps} lr {self.lr:.4g} loss {l[3]:.4f} (obj {l[0]:.4f} cls {l[1]:.4f} box {l[2]:.4f}) "
+                    f"loss_scale {self.loss_scale:g} skipped {self.skipped_steps}")
+        self._poll_nonfinite(wait=True)
+        return hist.cpu().numpy()
 
     def export_params(self):
         """-> dict in the weights.py format (masters + BatchNorm running statistics) for ObjectDetector(params, ...)."""

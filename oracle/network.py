@@ -74,6 +74,14 @@ def init_weights(seed: int = 2, num_classes: int = 20, neck_ch: int = NECK_CH, t
     return params
 
 
+def f16_weights(params):
+    """The model the device runs: conv weights rounded to f16 (what od_pack_weights stores), everything else f32.
+    init_weights() already returns f16-representable weights; TRAINED masters are f32 and need this before a comparison
+    that is about arithmetic, not about weight quantisation."""
+    return {k: (np.asarray(v, np.float32).astype(np.float16).astype(np.float32) if k.endswith(".w") else v)
+            for k, v in params.items()}
+
+
 def fold_bn(params, name):
     """(scale, bias) f32 of the fused epilogue: BN(x) = gamma*(x-mean)/sqrt(var+eps)+beta."""
     if name + ".gamma" in params:

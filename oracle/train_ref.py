@@ -32,6 +32,8 @@ class TorchDetector:
     def __init__(self, params, backbone_act=("leaky", 0.1), head_act=("elu", 1.0), dtype=torch.float64, slope_masks=None):
         self.slope_masks = slope_masks or {}
         self.flips, self.units = {}, {}
+        self.batch_stats = {}  # layer -> (batch mean, biased batch variance) of its last call, float64 [Cout]
+        self._run, self._mom = None, 0.99
         self.record_patterns = False  # True: forward() keeps this run's own sign pattern per leaky layer in .patterns
         self.patterns = {}
         self.p = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=not (k.endswith(".mean") or k.endswith(".var")))
@@ -45,6 +47,11 @@ class TorchDetector:
         if name + ".gamma" in self.p:
             mu = z.mean((0, 2, 3), keepdim=True)
             var = z.var((0, 2, 3), unbiased=False, keepdim=True)
+            self.batch_stats[name] = (mu.detach().reshape(-1).numpy().copy(), var.detach().reshape(-1).numpy().copy())
+            if self._run is not None:  # a layer shared by the three levels updates its statistics three times per pass
+                m, v = self._run[name]
+                bm, bv = self.batch_stats[name]
+                self._run[name] = (self._mom * m + (1 - self._mom) * bm, self._mom * v + (1 - self._mom) * bv)
             z = (z - mu) / torch.sqrt(var + BN_EPS)
             z = z * self.p[name + ".gamma"].view(1, -1, 1, 1) + self.p[name + ".beta"].view(1, -1, 1, 1)
         else:
@@ -87,6 +94,23 @@ class TorchDetector:
             o = self.conv(t, "h.out").permute(0, 2, 3, 1)
             outs.append(o.reshape(o.shape[0], -1, C))
         return torch.cat(outs, 1)
+
+    def running_stats_after(self, batches, momentum=0.99, num_classes=20):
+        """BatchNorm running statistics after forward passes over `batches` (list of uint8 [B,S,S,3]) with the parameters held
+        fixed: {layer: (run_mean, run_var)}.  Convention frozen for this build [BUILD-DEFINED, Keras' non-fused BatchNorm]:
+        moving = momentum * moving + (1 - momentum) * batch, with the BIASED (population) batch variance, momentum 0.99,
+        starting from the parameters' .mean / .var."""
+        self._run = {k[:-6]: (self.p[k[:-6] + ".mean"].detach().numpy().astype(np.float64).copy(),
+                              self.p[k[:-6] + ".var"].detach().numpy().astype(np.float64).copy())
+                     for k in self.p if k.endswith(".gamma")}
+        self._mom = momentum
+        try:
+            for x in batches:
+                with torch.no_grad():
+                    self.forward(x, num_classes)
+            return self._run
+        finally:
+            self._run = None
 
     def loss_and_grads(self, x_u8, y_target, num_classes=20, box_mode="smooth_l1"):
         pred = self.forward(x_u8, num_classes)
