@@ -386,6 +386,28 @@ int od_aug_params_bytes(void);
 int od_augment_batch(od_ctx* ctx, const uint8_t* src, const void* params, uint8_t* out, int B, int H, int W,
                      void* stream);
 
+/* Wide (f32) add paths of the mixed-precision inference plan (ObjectDetector(precision="mixed"); replaces the Keras `Add`
+ * layers of the residual blocks, reference docs/MODEL.md:15-17, where the reference's fp32 path keeps the sum in fp32):
+ *   v = y (+ res);  out32 = v;  out16 = f16(v);  out_hilo[r] = [f16(v) | f16(v - f16(v))]  (row of 2*C halves)
+ * y f32 [M,C] is the producing conv's f32 output; res is the f32 (res_f32 != 0) or f16 tensor it is added to -- the residual
+ * stream, or with res_up2 the half-size map of the FPN sum (docs/MODEL.md:5-8) -- or NULL;
+ * any of the three outputs may be NULL.  A conv over the [hi | lo] tensor with its weights repeated along Cin sees ~22
+ * significant bits of v on f16 MFMA operands. */
+typedef struct od_wide_desc {
+  const float* y;
+  const void* res;
+  float* out32;
+  void* out16;
+  void* out_hilo;
+  int64_t M;
+  int32_t C;
+  int32_t res_f32;
+  int32_t res_up2; /* != 0: res is [B, H/2, W/2, C] and every element adds its nearest-neighbour parent (the FPN sums) */
+  int32_t H, W;    /* the OUTPUT map (res_up2 only; M = B * H * W) */
+  int32_t pad_;
+} od_wide_desc;
+int od_wide_add(od_ctx* ctx, const od_wide_desc* d, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Native forward plan: the whole layer list of one network executed from C++ (one call per batch, optional
  * hipGraph replay) so Python is not in the per-layer loop.  ops is an array of od_plan_op.
@@ -394,6 +416,7 @@ int od_augment_batch(od_ctx* ctx, const uint8_t* src, const void* params, uint8_
 #define OD_OP_CONV_FIRST 2
 #define OD_OP_BNECK 3
 #define OD_OP_STEM 4
+#define OD_OP_WIDE 5
 
 typedef struct od_plan_op {
   int32_t kind; /* OD_OP_* */
@@ -401,6 +424,7 @@ typedef struct od_plan_op {
   od_conv_desc conv; /* OD_OP_CONV; OD_OP_CONV_FIRST uses x(u8), w, scale, bias, out, B,H,W,Cout,act,alpha */
   od_bneck_desc bneck; /* OD_OP_BNECK */
   od_stem_desc stem;   /* OD_OP_STEM */
+  od_wide_desc wide;   /* OD_OP_WIDE */
 } od_plan_op;
 
 typedef struct od_plan od_plan;

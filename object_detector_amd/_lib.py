@@ -15,7 +15,7 @@ LIB_PATH = _HERE / "libodhip.so"
 OD_ACT_LINEAR, OD_ACT_LEAKY, OD_ACT_ELU = 0, 1, 2
 OD_RES_NONE, OD_RES_SAME, OD_RES_UP2 = 0, 1, 2
 OD_DT_F16, OD_DT_F32, OD_DT_BF16 = 0, 1, 2
-OD_OP_CONV, OD_OP_CONV_FIRST, OD_OP_BNECK, OD_OP_STEM = 1, 2, 3, 4
+OD_OP_CONV, OD_OP_CONV_FIRST, OD_OP_BNECK, OD_OP_STEM, OD_OP_WIDE = 1, 2, 3, 4, 5
 
 ACT_ENUM = {None: OD_ACT_LINEAR, "linear": OD_ACT_LINEAR, "leaky": OD_ACT_LEAKY, "elu": OD_ACT_ELU}
 
@@ -82,12 +82,20 @@ class PackLayer(C.Structure):
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("ksize", C.c_int32), ("pad_", C.c_int32)]
 
 
+class WideDesc(C.Structure):
+    C_NAME = "od_wide_desc"  # the struct of include/odhip.h this mirrors (layout checked by tests/test_host_logic.py)
+    _fields_ = [("y", C.c_void_p), ("res", C.c_void_p), ("out32", C.c_void_p), ("out16", C.c_void_p),
+                ("out_hilo", C.c_void_p), ("M", C.c_int64), ("C", C.c_int32), ("res_f32", C.c_int32),
+                ("res_up2", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("pad_", C.c_int32)]
+
+
 class PlanOp(C.Structure):
     C_NAME = "od_plan_op"  # the struct of include/odhip.h this mirrors (layout checked by tests/test_host_logic.py)
-    _fields_ = [("kind", C.c_int32), ("pad_", C.c_int32), ("conv", ConvDesc), ("bneck", BneckDesc), ("stem", StemDesc)]
+    _fields_ = [("kind", C.c_int32), ("pad_", C.c_int32), ("conv", ConvDesc), ("bneck", BneckDesc), ("stem", StemDesc),
+                ("wide", WideDesc)]
 
 
-STRUCTS = (ConvDesc, AugParams, BneckDesc, StemDesc, SgdSeg, WgradRed, PackLayer, PlanOp)
+STRUCTS = (ConvDesc, AugParams, BneckDesc, StemDesc, SgdSeg, WgradRed, PackLayer, WideDesc, PlanOp)
 
 
 class OdError(RuntimeError):
@@ -111,6 +119,7 @@ _PROTOS = {
     "od_conv2d_fwd_bn_rows": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),
     "od_stem_supported": (C.c_int, [C.c_int, C.c_int]),
     "od_stem_fwd": (C.c_int, [C.c_void_p, C.POINTER(StemDesc), C.c_void_p]),
+    "od_wide_add": (C.c_int, [C.c_void_p, C.POINTER(WideDesc), C.c_void_p]),
     "od_bottleneck_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "od_bottleneck_fwd": (C.c_int, [C.c_void_p, C.POINTER(BneckDesc), C.c_void_p]),
     "od_conv_first_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -99,7 +99,11 @@ const std::vector<StructInfo>& od_struct_table() {
         OD_F(od_aug_params, erase), OD_F(od_aug_params, erase_rgb)}},
       {"od_plan_op", sizeof(od_plan_op),
        {OD_F(od_plan_op, kind), OD_F(od_plan_op, pad_), OD_F(od_plan_op, conv), OD_F(od_plan_op, bneck),
-        OD_F(od_plan_op, stem)}},
+        OD_F(od_plan_op, stem), OD_F(od_plan_op, wide)}},
+      {"od_wide_desc", sizeof(od_wide_desc),
+       {OD_F(od_wide_desc, y), OD_F(od_wide_desc, res), OD_F(od_wide_desc, out32), OD_F(od_wide_desc, out16),
+        OD_F(od_wide_desc, out_hilo), OD_F(od_wide_desc, M), OD_F(od_wide_desc, C), OD_F(od_wide_desc, res_f32),
+        OD_F(od_wide_desc, res_up2), OD_F(od_wide_desc, H), OD_F(od_wide_desc, W), OD_F(od_wide_desc, pad_)}},
   };
   return t;
 }
@@ -175,6 +179,7 @@ static int run_op(od_plan* pl, int i, hipStream_t s) {
   }
   if (op.kind == OD_OP_BNECK) return od_bottleneck_fwd(pl->ctx, &op.bneck, s);
   if (op.kind == OD_OP_STEM) return od_stem_fwd(pl->ctx, &op.stem, s);
+  if (op.kind == OD_OP_WIDE) return od_wide_add(pl->ctx, &op.wide, s);
   od_set_error("od_plan: unknown op kind %d at %d", op.kind, i);
   return OD_ERR_INVALID;
 }
@@ -211,6 +216,8 @@ extern "C" int od_plan_create(od_ctx* ctx, const od_plan_op* ops, int n_ops, od_
         return OD_ERR_INVALID;
       }
       pl->names[i] = od_bottleneck_kernel_name(ops[i].bneck.C);
+    } else if (ops[i].kind == OD_OP_WIDE) {
+      pl->names[i] = "od_wide_add_k";
     } else {
       od_set_error("od_plan_create: unknown op kind %d at %d", ops[i].kind, i);
       delete pl;

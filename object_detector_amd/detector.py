@@ -80,7 +80,7 @@ class _Pipeline:
 
 class ObjectDetector:
     def __init__(self, params, batch_size=16, input_size=(320, 320), keep_aspect=False, strict_nms=False,
-                 use_multi_gpu=True, device=None, prior_wh=None, n_inflight=None):
+                 use_multi_gpu=True, device=None, prior_wh=None, n_inflight=None, precision=None):
         if device is None:  # one process per GPU; the modulo only matters when several ranks rehearse on one GPU
             device = f"cuda:{int(os.environ.get('LOCAL_RANK', 0)) % max(1, torch.cuda.device_count())}"
         if not torch.cuda.is_available():
@@ -96,7 +96,10 @@ class ObjectDetector:
         kw = {} if prior_wh is None else {"prior_wh": prior_wh}
         self.pb = PriorBoxes(self.input_size, self.num_classes, device=self.device, **kw)
         n = int(n_inflight) if n_inflight is not None else int(os.environ.get("OD_INFLIGHT", 3))  # explicit argument wins
-        self.net = Net(params, self.batch_size, self.input_size, device=self.device, overlapped=n > 1)
+        # precision: "f16" (default, the throughput plan) or "mixed" (f32 residual stream + split operands in the last layers:
+        # north_star's 1e-3 logit tolerance at any logit scale, net.py); None = $OD_PRECISION or "f16"
+        self.net = Net(params, self.batch_size, self.input_size, device=self.device, overlapped=n > 1, precision=precision)
+        self.precision = self.net.precision
         assert self.net.P == len(self.pb)
         self.post = Postprocessor(self.batch_size, self.net.P, self.num_classes, self.pb.pb_locs, device=self.device,
                                   strict_nms=self.strict_nms, loc_scale=self.pb.loc_scale)
@@ -107,7 +110,8 @@ class ObjectDetector:
         self._pipes = [_Pipeline(self.net, self.post, torch.cuda.Stream(device=self.device))]
         for _ in range(max(1, n) - 1):
             net = Net(params, self.batch_size, self.input_size, device=self.device, overlapped=True,
-                      share_weights_with=self.net)
+                      share_weights_with=self.net, precision=self.precision, stream_stages=self.net.stream_stages,
+                      split=self.net.split, wide_fpn=self.net.wide_fpn)
             post = Postprocessor(self.batch_size, net.P, self.num_classes, self.pb.pb_locs, device=self.device,
                                  strict_nms=self.strict_nms, loc_scale=self.pb.loc_scale)
             self._pipes.append(_Pipeline(net, post, torch.cuda.Stream(device=self.device)))

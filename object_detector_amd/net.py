@@ -66,9 +66,44 @@ def pad_vec(v: np.ndarray, n: int):
     return out
 
 
+# the cheapest plan that keeps EVERY logit within 1e-3 x scale of the fp32 oracle at 32 x 320^2 / 16 x 640^2 with margin
+# (profiles/r03/logit_error_mixed_plans_cpu.txt: 22 % of the default plan's error variance; the stage-3 stream would cost
+# another 0.29 ms per batch for 6 points of variance that splitting the two small lateral layers buys for nothing)
+MIXED_STREAM_STAGES = (4, 5)
+MIXED_SPLIT = ("n.lat4", "n.lat5", "n.out3", "n.out4", "h.t0", "h.out")
+# who reads a neck / head tensor as a convolution operand (producer layer -> consumer layers)
+_NECK_CONSUMERS = {"n.lat5": ("h.t0",), "n.lat4": ("n.out4",), "n.out4": ("h.t0",), "n.lat3": ("n.out3",), "n.out3": ("h.t0",),
+                   "h.t0": ("h.out",)}
+
+
 class Net:
+    """precision="f16" (default): every stored activation is f16 -- the throughput plan.
+    precision="mixed": north_star's "within 1e-3 on logits" at ANY logit scale (measured attribution: DESIGN.md §5,
+    scripts/dev/attribute_logit_error*.py): the residual stream of `stream_stages` is kept in f32 (od_wide_add: x32 += y32,
+    the next conv's f16 operand is rounded once from the f32 sum) and the convolutions in `split` read their input as an f16
+    (hi, lo) pair (2x the MFMA work of those layers, ~22 significant bits).  Every multiply is still an f16 MFMA."""
+
     def __init__(self, params, batch_size, input_size=(320, 320), device="cuda:0", backbone_act=("leaky", 0.1),
-                 head_act=("elu", 1.0), tile_cfg=None, overlapped=False, share_weights_with=None):
+                 head_act=("elu", 1.0), tile_cfg=None, overlapped=False, share_weights_with=None, precision=None,
+                 stream_stages=None, split=None, wide_fpn=None):
+        self.wide_fpn = (os.environ.get("OD_MIXED_WIDE_FPN", "1") != "0") if wide_fpn is None else bool(wide_fpn)
+        self.precision = precision or os.environ.get("OD_PRECISION", "f16")
+        if self.precision not in ("f16", "mixed"):
+            raise ValueError(f"precision must be 'f16' or 'mixed', got {self.precision!r}")
+        env_st, env_sp = os.environ.get("OD_MIXED_STREAM"), os.environ.get("OD_MIXED_SPLIT")
+        self.stream_stages = tuple(stream_stages if stream_stages is not None else
+                                   ([int(v) for v in env_st.split(",") if v] if env_st is not None else MIXED_STREAM_STAGES))
+        self.split = tuple(split if split is not None else
+                           ([v for v in env_sp.split(",") if v] if env_sp is not None else MIXED_SPLIT))
+        if self.precision == "f16":
+            self.stream_stages, self.split, self.wide_fpn = (), (), False
+        if any(k not in (3, 4, 5) for k in self.stream_stages):
+            raise ValueError("stream_stages: stages 3, 4, 5 only (stages 1-2 run as fused residual blocks)")
+        for nm in self.split:
+            if nm not in ("n.lat3", "n.lat4", "n.lat5", "n.out3", "n.out4", "h.t0", "h.out"):
+                raise ValueError(f"split: {nm!r} is not a neck / prediction-module layer")
+            if nm.startswith("n.lat") and int(nm[-1]) not in self.stream_stages:
+                raise ValueError(f"split layer {nm} reads the stage-{nm[-1]} tap: that stage must be in stream_stages")
         self.ctx = Context.get(device)
         self.lib = self.ctx.lib
         self.device = torch.device(device)
@@ -106,10 +141,13 @@ class Net:
                 wp = pack_conv_weight(w)
                 npad = wp.shape[0]
             self._dev[name] = (self._to_dev(wp), self._to_dev(pad_vec(scale, npad)), self._to_dev(pad_vec(bias, npad)))
+            if name in self.split:  # operand = [hi | lo] along the channels: the same weights for both halves
+                self._dev[name + "#split"] = (self._to_dev(pack_conv_weight(np.concatenate([w, w], axis=3))),) + self._dev[name][1:]
         self.input = torch.zeros((self.B, self.H, self.W, 3), dtype=torch.uint8, device=self.device)
         self.pred = torch.zeros((self.B, self.P, self.C), dtype=torch.float32, device=self.device)
         self.ops = []       # (_lib.PlanOp)
         self.op_info = []   # dict(name, flops, bytes)
+        self._hilo = {}     # (hi, lo) pairs of the backbone taps (mixed precision, split lateral layers)
         self._build(backbone_act, head_act)
         if self._splitk_elems:
             nbytes = min(32 * self._splitk_elems * 4, 256 << 20)  # room for up to 32 partial slabs of the largest layer
@@ -148,12 +186,68 @@ class Net:
         self._keep.append(t)
         return t
 
+    def _buf32(self, h, w, c):
+        t = torch.empty((self.B, h, w, c), dtype=torch.float32, device=self.device)
+        self._keep.append(t)
+        return t
+
+    def _wide(self, name, y32, res, res_f32, out32, out16, hilo, h, w, c, up2=False):
+        """od_wide_add as a plan op: v = y32 (+ res, or + its nearest-neighbour parent on the half-size map `res` with
+        up2); out32 = v, out16 = f16(v), hilo = [f16(v) | f16(v - f16(v))]."""
+        d = _lib.WideDesc()
+        d.y = y32.data_ptr()
+        d.res = res.data_ptr() if res is not None else None
+        d.out32 = out32.data_ptr() if out32 is not None else None
+        d.out16 = out16.data_ptr() if out16 is not None else None
+        d.out_hilo = hilo.data_ptr() if hilo is not None else None
+        d.M, d.C, d.res_f32 = self.B * h * w, c, int(bool(res_f32))
+        d.res_up2, d.H, d.W = int(bool(up2)), h, w
+        op = _lib.PlanOp()
+        op.kind = _lib.OD_OP_WIDE
+        op.wide = d
+        self.ops.append(op)
+        m = self.B * h * w
+        nbytes = m * c * (4 + (0 if res is None else (4 if res_f32 else 2)) + (4 if out32 is not None else 0)
+                          + (2 if out16 is not None else 0) + (4 if hilo is not None else 0))
+        self.op_info.append(dict(name=name, flops=0.0, bytes=float(nbytes), shape=(m, c, 0), kind="wide", y=y32, res=res,
+                                 res_f32=bool(res_f32), out32=out32, out16=out16, hilo=hilo))
+
+    def _neck_conv(self, name, x, x_hilo, h, w, cin, cout, k, act, up16=None, up32=None, need16=False, keep32=False,
+                   consumers=None):
+        """One neck / prediction-module layer of either plan -> (out f16 or None, out [hi | lo] or None, out f32 or None).
+        The layer READS the (hi, lo) pair when it is a split layer.  It WRITES a pair (f32 conv output + od_wide_add) when
+        one of its consumers is a split layer, and a plain f16 tensor when a consumer is not (or need16).  up16 / up32: the
+        half-size map of an FPN sum -- f16 in the conv's own epilogue (default plan), or f32 in od_wide_add (mixed plan:
+        the sum is formed in f32 and rounded once).  keep32: the f32 output is itself the operand of a later f32 sum."""
+        consumers = _NECK_CONSUMERS.get(name, ()) if consumers is None else consumers
+        want_hilo = any(c in self.split for c in consumers)
+        want16 = need16 or any(c not in self.split for c in consumers)
+        src, cin_eff, wkey = x, cin, None
+        if name in self.split:
+            if x_hilo is None:
+                raise ValueError(f"split layer {name}: its input has no (hi, lo) pair")
+            src, cin_eff, wkey = x_hilo, 2 * cin, name + "#split"
+        if not want_hilo and up32 is None and not keep32:
+            out, _, _ = self._conv(name, src, h, w, cin_eff, cout, k, 1, act, res=up16,
+                                   res_mode=_lib.OD_RES_UP2 if up16 is not None else _lib.OD_RES_NONE, wkey=wkey)
+            return out, None, None
+        y32 = self._buf32(h, w, cout)
+        in_epilogue = up16 if up32 is None else None
+        self._conv(name, src, h, w, cin_eff, cout, k, 1, act, res=in_epilogue,
+                   res_mode=_lib.OD_RES_UP2 if in_epilogue is not None else _lib.OD_RES_NONE, out=y32, out_f32=True, wkey=wkey)
+        out16 = self._buf(h, w, cout) if want16 else None
+        hilo = self._buf(h, w, 2 * cout) if want_hilo else None
+        s32 = self._buf32(h, w, cout) if (keep32 and up32 is not None) else None
+        if out16 is not None or hilo is not None or s32 is not None:
+            self._wide(name + ".wide", y32, up32, True, s32, out16, hilo, h, w, cout, up2=up32 is not None)
+        return out16, hilo, (s32 if s32 is not None else y32)
+
     def _conv(self, name, x, h, w, cin, cout, k, stride, act, res=None, res_mode=_lib.OD_RES_NONE, out=None,
-              out_f32=False, obs=0, ops=0, then=None):
+              out_f32=False, obs=0, ops=0, then=None, wkey=None):
         """then = (name2, cout2, act2): the pointwise layer that consumes this layer's output rides in the same op
         (od_conv_desc.w2: inside the 8-wave kernel's epilogue, or as a second launch of the library's choosing);
         returns (out, ho, wo, out2) then."""
-        wt, sc, bi = self._dev[name]
+        wt, sc, bi = self._dev[wkey or name]
         ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
         if out is None:
             out = self._buf(ho, wo, cout)
@@ -197,6 +291,9 @@ class Net:
                                  # the op's tensors, for per-layer parity checks (tests/test_gpu_fullsize.py)
                                  kind="conv", x=x, res=res, res_mode=res_mode, out=None if isinstance(out, int) else out,
                                  stride=stride, ksize=k, act=act, out_f32=out_f32))
+        if wkey is not None and wkey.endswith("#split"):  # algorithmic flops: the (hi, lo) pair is ONE operand
+            self.op_info[-1]["flops"] *= 0.5
+            self.op_info[-1]["split"] = True
         if then is not None:
             inf = self.op_info[-1]
             inf["flops"] += 2.0 * m * cout2 * cout
@@ -274,6 +371,11 @@ class Net:
             # 256-channel stage: a block's 1x1 (256 -> 128) rides in the launch that PRODUCES its input (the stride-2 conv
             # or the previous block's 3x3 -- all 256 channels of a pixel are in one workgroup of the 8-wave kernel)
             ride = self.fuse_blocks and ch == 256 and not fused_block and os.environ.get("OD_FUSE_POINTWISE", "1") != "0"
+            wide = si in self.stream_stages  # f32 residual stream (precision="mixed")
+            if wide:
+                ride = False  # a block's 1x1 reads the f16 copy that od_wide_add rounds from the f32 sum
+                hilo_tap = f"n.lat{si}" in self.split
+                x32 = y32 = None
             t = None
             if si == 1 and fuse_stem:
                 h, w = h // 2, w // 2
@@ -287,7 +389,21 @@ class Net:
                     continue
                 if t is None:
                     t, _, _ = self._conv(f"b.s{si}.{r}.a", x, h, w, ch, ch // 2, 1, 1, bact)
-                if ride and r + 1 < n:
+                if wide:
+                    # y32 = act(bn(conv3x3(t))) as f32; x32 (+)= y32; x = f16(x32) (rounded once from the f32 sum)
+                    if y32 is None:
+                        y32 = self._buf32(h, w, ch)
+                        x32 = self._buf32(h, w, ch)
+                    self._conv(f"b.s{si}.{r}.b", t, h, w, ch // 2, ch, 3, 1, bact, out=y32, out_f32=True)
+                    last = r + 1 == n
+                    xn = self._buf(h, w, ch)
+                    hl = self._buf(h, w, 2 * ch) if (last and hilo_tap) else None
+                    self._wide(f"b.s{si}.{r}.add", y32, x if r == 0 else x32, r != 0, x32, xn, hl, h, w, ch)
+                    x = xn
+                    if hl is not None:
+                        self._hilo[f"tap{si}"] = hl
+                    t = None
+                elif ride and r + 1 < n:
                     x, _, _, t = self._conv(f"b.s{si}.{r}.b", t, h, w, ch // 2, ch, 3, 1, bact, res=x,
                                             res_mode=_lib.OD_RES_SAME, then=(f"b.s{si}.{r + 1}.a", ch // 2, bact))
                 else:
@@ -298,23 +414,32 @@ class Net:
             taps.append((x, h, w, ch))
         (c3, h3, w3, ch3), (c4, h4, w4, ch4), (c5, h5, w5, ch5) = taps[2], taps[3], taps[4]
         nc = self.neck_ch
-        p5, _, _ = self._conv("n.lat5", c5, h5, w5, ch5, nc, 1, 1, hact)
-        m4, _, _ = self._conv("n.lat4", c4, h4, w4, ch4, nc, 1, 1, hact, res=p5, res_mode=_lib.OD_RES_UP2)
-        p4, _, _ = self._conv("n.out4", m4, h4, w4, nc, nc, 3, 1, hact)
-        m3, _, _ = self._conv("n.lat3", c3, h3, w3, ch3, nc, 1, 1, hact, res=p4, res_mode=_lib.OD_RES_UP2)
-        p3, _, _ = self._conv("n.out3", m3, h3, w3, nc, nc, 3, 1, hact)
+        # FPN sums (docs/MODEL.md:5-8): in the mixed plan they are formed in f32 (od_wide_add adds the f32 half-size map)
+        wf = self.precision == "mixed" and self.wide_fpn
+        p5, p5s, p5w = self._neck_conv("n.lat5", c5, self._hilo.get("tap5"), h5, w5, ch5, nc, 1, hact, need16=not wf, keep32=wf)
+        m4, m4s, _ = self._neck_conv("n.lat4", c4, self._hilo.get("tap4"), h4, w4, ch4, nc, 1, hact,
+                                     up16=None if wf else p5, up32=p5w if wf else None)
+        p4, p4s, p4w = self._neck_conv("n.out4", m4, m4s, h4, w4, nc, nc, 3, hact, need16=not wf, keep32=wf)
+        m3, m3s, _ = self._neck_conv("n.lat3", c3, self._hilo.get("tap3"), h3, w3, ch3, nc, 1, hact,
+                                     up16=None if wf else p4, up32=p4w if wf else None)
+        p3, p3s, _ = self._neck_conv("n.out3", m3, m3s, h3, w3, nc, nc, 3, hact)
         self.levels = [(p3, h3, w3), (p4, h4, w4), (p5, h5, w5)]
         self.taps = [c3, c4, c5]
         # shared prediction module; the last conv writes f32 logits into pred[:, off:off+h*w*8, :]
         off = 0
         cout = W.NUM_PRIORS * self.C
-        for (x, h, w) in self.levels:
-            t = x
+        for (x, h, w), xs in zip(self.levels, (p3s, p4s, p5s)):
+            t, ts = x, xs
             for i in range(self.tower):
-                t, _, _ = self._conv(f"h.t{i}", t, h, w, nc, nc, 3, 1, hact)
+                t, ts, _ = self._neck_conv(f"h.t{i}", t, ts, h, w, nc, nc, 3, hact,
+                                           consumers=(f"h.t{i + 1}",) if i + 1 < self.tower else ("h.out",))
             out_ptr = self.pred.data_ptr() + off * self.C * 4
-            self._conv("h.out", t, h, w, nc, cout, 3, 1, None, out=out_ptr, out_f32=True,
-                       obs=self.P * self.C, ops=cout)
+            if "h.out" in self.split:
+                self._conv("h.out", ts, h, w, 2 * nc, cout, 3, 1, None, out=out_ptr, out_f32=True,
+                           obs=self.P * self.C, ops=cout, wkey="h.out#split")
+            else:
+                self._conv("h.out", t, h, w, nc, cout, 3, 1, None, out=out_ptr, out_f32=True,
+                           obs=self.P * self.C, ops=cout)
             self.op_info[-1]["pred_rows"] = (off, h * w * W.NUM_PRIORS)
             off += h * w * W.NUM_PRIORS
         assert off == self.P

@@ -47,4 +47,7 @@ def assert_logits(rec, tag):
     assert rec["rms_rel_scale"] <= 3e-4, rec
     assert rec["max_over_sigma"] <= rec["gaussian_max_over_sigma"] + 3.0, rec
     assert rec["rms_dev_vs_fp32"] <= 1.15 * rec["rms_f16oracle_vs_fp32"], rec
-    assert rec["max_dev_vs_fp32"] <= 2e-2 * rec["logit_scale"], rec
+    # every logit of the DEFAULT (f16-storage) plan within 3e-3 x scale of the plain fp32 oracle (measured 1.4-1.5e-3 over
+    # 14 / 28 M logits of a random-init network, 3.3e-4 with trained weights); precision="mixed" is held to north_star's
+    # 1e-3 x scale on EVERY logit (tests/test_gpu_mixed_precision.py)
+    assert rec["max_dev_vs_fp32"] <= 3e-3 * rec["logit_scale"], rec

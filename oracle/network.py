@@ -126,42 +126,98 @@ def conv_nhwc_numpy(x, w_ohwi, stride):
     return out
 
 
+class MixedPlan:
+    """The three predicates that restate object_detector_amd.net's precision="mixed" plan for Runner:
+      storage(name)     -> True: that layer's OUTPUT is rounded to f16 where it is stored
+      operand_f16(name) -> True: that layer's INPUT is rounded to f16 before the multiply (every layer but the split ones,
+                           whose (hi, lo) operand pair carries ~22 bits: modelled as the unrounded f32 value)
+      res_f16(name)     -> True: the residual operand is the f16 copy (the FPN up2 adds); False: the f32 residual stream
+    A residual-stream tensor of `stream_stages` is f32; the first block of a stage adds to the (f16) stride-2 conv output.
+    A neck / head tensor is kept f32 iff one of its consumers is a split layer."""
+    CONSUMERS = {"n.lat5": ("h.t0",), "n.lat4": ("n.out4",), "n.out4": ("h.t0",), "n.lat3": ("n.out3",), "n.out3": ("h.t0",),
+                 "h.t0": ("h.out",)}
+
+    def __init__(self, stream_stages=(4, 5), split=("n.lat4", "n.lat5", "n.out3", "n.out4", "h.t0", "h.out"), wide_fpn=True):
+        """wide_fpn: the two FPN sums lat(c) + up2(p) are formed in f32 from the f32 half-size map (else the conv epilogue
+        adds the f16 copy)."""
+        self.stream_stages, self.split, self.wide_fpn = tuple(stream_stages), tuple(split), bool(wide_fpn)
+
+    def _on_stream(self, name):
+        return any(name.startswith(f"b.s{k}.") and name.endswith(".b") for k in self.stream_stages)
+
+    def storage(self, name):
+        if self._on_stream(name):
+            return False
+        if any(c in self.split for c in self.CONSUMERS.get(name, ())):
+            return False
+        if self.wide_fpn and name in ("n.lat5", "n.out4"):  # kept f32 as the operand of the next FPN sum
+            return False
+        return True
+
+    def operand_f16(self, name):
+        return name not in self.split
+
+    def res_f16(self, name):
+        if self.wide_fpn and name in ("n.lat4", "n.lat3"):
+            return False
+        return not self._on_stream(name)
+
+    def runner(self, params, **kw):
+        return Runner(params, storage=self.storage, operand_f16=self.operand_f16, res_f16=self.res_f16, **kw)
+
+
 class Runner:
     """Layer-by-layer forward with the fused-epilogue semantics of od_conv2d_fwd (include/odhip.h)."""
 
-    def __init__(self, params, storage="f16", precise=False, backbone_act=("leaky", 0.1), head_act=("elu", 1.0)):
+    def __init__(self, params, storage="f16", precise=False, backbone_act=("leaky", 0.1), head_act=("elu", 1.0),
+                 operand_f16=None, res_f16=None):
+        """operand_f16: predicate layer name -> bool; True = that conv's INPUT is rounded to f16 before the multiply even when
+        the tensor is stored wider (a wide residual stream whose convolutions still run on f16 MFMA operands); a layer for
+        which it is False multiplies the stored values as they are (f32 storage + False = a hi/lo split-operand conv)."""
         self.p = params
+        self.operand_f16 = operand_f16
+        self.res_f16 = res_f16  # predicate: the residual operand of that layer is read as f16 (see MixedPlan)
+        self.trace = None  # set to {} to record every layer's stored output: name -> [array per call] (debugging aid)
         self.storage = storage
         self.dtype = torch.float64 if precise else torch.float32
         self.backbone_act = backbone_act
         self.head_act = head_act
 
-    def _store(self, y):
+    def _store(self, y, name=None):
+        """storage: "f32", "f16", or a predicate name -> bool choosing per layer OUTPUT whether it is rounded to f16 (error
+        attribution: scripts/dev/attribute_logit_error.py; mixed-precision plans: object_detector_amd.net f32_layers)."""
         y = y.astype(np.float32)
-        if self.storage == "f16":
+        if self.storage == "f16" or (callable(self.storage) and self.storage(name)):
             return y.astype(np.float16).astype(np.float32)
         return y
 
     def conv(self, x, name, stride=1, act=None, res=None, res_up2=False, store=True):
         w = self.p[name + ".w"]
         scale, bias = fold_bn(self.p, name)
+        if self.operand_f16 is not None and self.operand_f16(name):
+            x = x.astype(np.float16).astype(np.float32)
         y = conv_nhwc(x, w, stride, self.dtype).astype(np.float32)
         y = y * scale + bias
         if act is not None:
             y = _act(y, act[0], act[1])
         if res is not None:
             r = res
+            if self.res_f16 is not None and self.res_f16(name):
+                r = r.astype(np.float16).astype(np.float32)
             if res_up2:
-                r = np.repeat(np.repeat(res, 2, axis=1), 2, axis=2)
+                r = np.repeat(np.repeat(r, 2, axis=1), 2, axis=2)
             y = y + r
-        return self._store(y) if store else y.astype(np.float32)
+        out = self._store(y, name) if store else y.astype(np.float32)
+        if self.trace is not None:
+            self.trace.setdefault(name, []).append(out)
+        return out
 
     def first(self, x_u8, name="b.conv0"):
         w = self.p[name + ".w"]
         scale, bias = fold_bn(self.p, name)
         y = conv_nhwc(x_u8.astype(np.float32), w, 1, self.dtype).astype(np.float32)
         y = y * (scale / np.float32(255.0)).astype(np.float32) + bias
-        return self._store(_act(y, *self.backbone_act))
+        return self._store(_act(y, *self.backbone_act), name)
 
     def backbone(self, x_u8):
         a = self.backbone_act

@@ -275,7 +275,7 @@ def test_training_step_at_baseline_config(cuda, B, S):
                                    worst_grad_rel=top[:6], median_grad_rel=float(np.median(list(worst.values()))),
                                    oracle_seconds=round(t_oracle, 1), oracle_dtype="f32"))
     assert flips / units < 0.02
-    assert top[0][1] < 0.02, top[:6]
+    assert top[0][1] < 0.01, top[:6]  # measured 0.53 % (32 x 320^2) / 0.65 % (16 x 640^2) against the f32 oracle
     # and the whole step (all-reduce no-op at world 1, SGD, re-pack) runs at this size and leaves finite parameters
     tr.lr = 1e-3
     tr.step(torch.from_numpy(x).to(cuda), anns)
