@@ -55,13 +55,9 @@ def parse():
 def launch_ranks(a):
     """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks OURSELVES (one process per GPU,
     `torch.distributed.run`, rendezvous on 127.0.0.1) and forward their output and exit code.  This parent has not made
-    and will not make a GPU call (torch.cuda.device_count() does not initialise the runtime), so nothing that touched the
-    GPU is ever re-executed.  The knob this stands for is the reference's use_multi_gpu=True (voc_validate.py:26)."""
-    import socket
+    and will not make a GPU call besides counting the devices, and it only ever SPAWNS children (it never replaces itself
+    with another program), so nothing that touched the GPU is ever re-executed.  The knob this stands for is the reference's use_multi_gpu=True (voc_validate.py:26)."""
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ndev = torch.cuda.device_count()
@@ -70,8 +66,9 @@ def launch_ranks(a):
         print(f"bench.py: {a.gpus} ranks on {ndev} GPU(s): rehearsal with the gloo backend (ranks share a device)",
               file=sys.stderr)
         env["OD_BENCH_BACKEND"] = "gloo"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun's own c10d rendezvous picks the port (no bind-then-close race with other processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={a.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -275,6 +272,73 @@ def extra_block(params, a, dev):
     return out
 
 
+XGMI_MESH_GBS = 7 * 153.0  # per GPU: 7 point-to-point links x ~153 GB/s (guides/MI355X_MICROARCH.md)
+
+
+def multi_rank_train_block(params, a, rank, world, dev, backend):
+    """N > 1 only: the path's ONE collective, timed on all N ranks inside the driver's default command (the headline stays
+    inference, which has no data-path collective).  Training step of BASELINE.json configs[3] (32 x 320^2 per GPU) with the
+    f32 and the bf16 gradient payload, bucketed-and-overlapped vs one collective after backward, and the all-reduce alone on
+    the flat gradient buffer (173 MB f32 / 87 MB bf16) with its bus bandwidth against the 7-link xGMI mesh."""
+    import ctypes as C
+    from object_detector_amd import _lib
+    from object_detector_amd.net import Context
+    from object_detector_amd.trainer import init_comm
+    ctx = Context.get(dev)
+    comm, seen = None, torch.distributed.get_world_size()
+    if backend == "nccl":
+        comm, _ = init_comm(ctx)  # RCCL communicator through the C ABI (od_comm_*); the id travels over the process group
+        r_, n_ = C.c_int(), C.c_int()
+        _lib.check(ctx.lib.od_comm_count(comm, C.byref(r_), C.byref(n_)), "od_comm_count")
+        seen = n_.value
+        assert seen == world and r_.value == rank, f"RCCL reports rank {r_.value} of {seen}, launcher said {rank} of {world}"
+    size, batch = 320, 32
+    out = {"workload": f"Darknet53 {size}x{size} training step, batch {batch} per GPU (global {world * batch}), "
+                       f"data-parallel gradient all-reduce", "collective": "od_allreduce (RCCL)" if comm is not None else
+           f"torch.distributed {backend} (rehearsal: ranks share a GPU)", "od_comm_count": seen}
+    saved = os.environ.get("OD_TRAIN_BUCKET_MB")
+    try:
+        for payload in ("f32", "bf16"):
+            for bucket_mb, tag in ((32, "bucketed"), (0, "single")):
+                os.environ["OD_TRAIN_BUCKET_MB"] = str(bucket_mb)
+                rec, tr = run_train(params, size, batch, 6, 2, 3, rank, world, dev, comm, payload)
+                key = f"step_{payload}_{tag}"
+                out[key] = {"images_per_sec": rec["value"], "ms_per_step": rec["ms_per_step"],
+                            "ms_per_step_reps": rec["ms_per_step_reps"], "collectives_per_step": max(1, rec["gradient_buckets"]),
+                            "skipped_steps": rec["skipped_steps"]}
+                if tag == "single":  # the all-reduce alone, on the same buffer and stream, 10 in a row between events
+                    _barrier(world)
+                    for _ in range(2):
+                        tr._reduce_range(0, tr.n_flat)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    _barrier(world)
+                    e0.record()
+                    for _ in range(10):
+                        tr._reduce_range(0, tr.n_flat)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    t = torch.tensor([e0.elapsed_time(e1) / 10.0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                    ms = float(t.item())
+                    nbytes = tr.n_flat * (4 if payload == "f32" else 2)
+                    busbw = 2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9
+                    out[f"allreduce_only_{payload}"] = {
+                        "bytes": nbytes, "ms": round(ms, 4), "algbw_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                        "busbw_GBps": round(busbw, 1), "xgmi_mesh_GBps": XGMI_MESH_GBS, "frac_of_mesh": round(busbw / XGMI_MESH_GBS, 4),
+                        "includes_bf16_casts": payload == "bf16"}
+                del tr
+                torch.cuda.empty_cache()
+    finally:
+        if saved is None:
+            os.environ.pop("OD_TRAIN_BUCKET_MB", None)
+        else:
+            os.environ["OD_TRAIN_BUCKET_MB"] = saved
+    if comm is not None:
+        torch.cuda.synchronize()
+        ctx.lib.od_comm_destroy(comm)
+    return out
+
+
 def _workgroups(kernel_name, M, N):
     """Workgroups of one launch, from the tile shape in the kernel's template arguments (0 = unknown)."""
     import re
@@ -327,6 +391,7 @@ def main():
         ranks_seen = int(round(float(t.item())))
         assert ranks_seen == torch.distributed.get_world_size() == world
     keep_count = od.post.keep_count.cpu().numpy()
+    n_inflight = od.n_inflight
 
     # ---- roofline of the dominant kernel: hipEvents around every op of the plan, on the launch stream ----------
     reps = 5
@@ -386,6 +451,11 @@ def main():
             print(f"  {k:40s} n={v['n']:3d} {v['ms']:8.3f} ms {v['flops'] / (v['ms'] * 1e-3) / 1e12:8.1f} TF/s",
                   file=sys.stderr)
 
+    train_block = None
+    if world > 1 and not a.no_extra:  # every rank takes part in the collectives; rank 0 prints
+        del od
+        torch.cuda.empty_cache()
+        train_block = multi_rank_train_block(params, a, rank, world, dev, backend)
     if rank == 0:
         total_images = world * batch * a.steps
         out = {
@@ -407,7 +477,7 @@ def main():
                                    f"top-k + NMS), batch {batch} per GPU, synthetic VOC-shaped uint8 input, "
                                    f"random-init weights",
                        "global_batch": world * batch, "input_size": size, "parallelism": f"dp{world}",
-                       "graph": bool(a.graph), "batches_in_flight": od.n_inflight,
+                       "graph": bool(a.graph), "batches_in_flight": n_inflight,
                        "ranks_seen_by_process_group": ranks_seen, "backend": backend if world > 1 else None,
                        "kept_boxes_rank0_img0": int(keep_count[0])},
             "roofline": {"bound": "mfma", "kernel": dom, "launches_per_step": g["n"],
@@ -434,6 +504,8 @@ def main():
             del od
             torch.cuda.empty_cache()
             out["extra"] = extra_block(params, a, dev)
+        if train_block is not None:
+            out["train"] = train_block
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

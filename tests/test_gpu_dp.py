@@ -16,8 +16,17 @@ pytestmark = pytest.mark.gpu
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 
 
-def _launch(world, port, args, cwd=None, script=None, extra_env=None):
+def _free_port():
+    """A port that is free NOW, chosen by the kernel (a fixed port number fails the whole test when something else holds it)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _launch(world, args, cwd=None, script=None, extra_env=None):
     procs = []
+    port = _free_port()
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
@@ -52,7 +61,7 @@ def sequential_shards(cuda):
 
 def test_two_ranks_bucketed_allreduce_equals_sum_of_shards(cuda, sequential_shards, tmp_path):
     (g0, g1), seg, params0, D = sequential_shards
-    _launch(2, 29811, [str(tmp_path), "f32", "8"])
+    _launch(2, [str(tmp_path), "f32", "8"])
     r0 = np.load(tmp_path / "rank0_f32_8.npz")
     r1 = np.load(tmp_path / "rank1_f32_8.npz")
     assert int(r0["nbuckets"]) >= 4
@@ -70,14 +79,14 @@ def test_two_ranks_bucketed_allreduce_equals_sum_of_shards(cuda, sequential_shar
         step = D.LR * lr_multiplier(name) * want[o:o + n] / (D.LS * 2)
         np.testing.assert_allclose(r0["params"][o:o + n], params0[o:o + n] - step, rtol=1e-5, atol=1e-7)
     # one collective after backward instead of overlapped buckets: same numbers
-    _launch(2, 29813, [str(tmp_path), "f32", "0"])
+    _launch(2, [str(tmp_path), "f32", "0"])
     assert np.array_equal(np.load(tmp_path / "rank0_f32_0.npz")["grads"][mask], r0["grads"][mask])
 
 
 def test_two_ranks_bf16_payload_cost(cuda, sequential_shards, tmp_path):
     """BASELINE.json configs[4]: bf16 gradient payload.  Its accuracy cost against the f32 payload, per parameter segment."""
     (g0, g1), seg, _p0, D = sequential_shards
-    _launch(2, 29815, [str(tmp_path), "bf16", "8"])
+    _launch(2, [str(tmp_path), "bf16", "8"])
     r0 = np.load(tmp_path / "rank0_bf16_8.npz")
     r1 = np.load(tmp_path / "rank1_bf16_8.npz")
     assert np.array_equal(r0["grads"], r1["grads"]) and np.array_equal(r0["params"], r1["params"])
@@ -102,7 +111,7 @@ def test_voc_validate_two_ranks(cuda, tmp_path):
     r = subprocess.run([sys.executable, str(ROOT / "scripts" / "voc_validate.py"), "--result-dir", str(one)] + args,
                        capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
-    _launch(2, 29817, ["--result-dir", str(two)] + args, cwd=str(tmp_path), script=ROOT / "scripts" / "voc_validate.py",
+    _launch(2, ["--result-dir", str(two)] + args, cwd=str(tmp_path), script=ROOT / "scripts" / "voc_validate.py",
             extra_env={"OD_DIST_BACKEND": "gloo"})
     get = lambda p: [ln.split("] ", 1)[1] for ln in (p / "validate.log").read_text().splitlines() if "mAP=" in ln]
     assert len(get(two)) == 1 and get(two) == get(one), (get(one), get(two))
