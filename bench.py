@@ -391,7 +391,7 @@ def main():
         ranks_seen = int(round(float(t.item())))
         assert ranks_seen == torch.distributed.get_world_size() == world
     keep_count = od.post.keep_count.cpu().numpy()
-    n_inflight = od.n_inflight
+    n_inflight, precision, ablated = od.n_inflight, od.precision, od.net.ablated
 
     # ---- roofline of the dominant kernel: hipEvents around every op of the plan, on the launch stream ----------
     reps = 5
@@ -479,7 +479,8 @@ def main():
                        "global_batch": world * batch, "input_size": size, "parallelism": f"dp{world}",
                        "graph": bool(a.graph), "batches_in_flight": n_inflight,
                        "ranks_seen_by_process_group": ranks_seen, "backend": backend if world > 1 else None,
-                       "kept_boxes_rank0_img0": int(keep_count[0])},
+                       "kept_boxes_rank0_img0": int(keep_count[0]), "precision": precision,
+                       **({"ABLATED_TIMING_ONLY": os.environ.get("OD_ABLATE_OPS")} if ablated else {})},
             "roofline": {"bound": "mfma", "kernel": dom, "launches_per_step": g["n"],
                          "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F16_TFLOPS, 4),

@@ -282,15 +282,9 @@ struct ConvKernelInfo {
   int BM, BN, threads;
 };
 
-// conv_win.hip: LDS-window direct 3x3 / stride-1 kernels.  Returns false when the shape cannot use variant `idx`.
-int od_conv_win_num_cfgs();
-// conv_pw.hip: persistent wave-specialised window kernel (one variant)
-bool od_conv_pw_select(const ConvKP& p, int num_cu, ConvKernelInfo* info, size_t* lds_bytes, int* np_out, int* grid,
-                       int* ntiles_total);
 // conv_8ph.hip: 8-wave, BM x 256 tile, one workgroup per CU, staggered wave groups (3x3 and 1x1)
 int od_conv_8ph_num_cfgs();
 bool od_conv_8ph_select(int idx, const ConvKP& p, int ksize, ConvKernelInfo* info, size_t* lds_bytes);
-bool od_conv_win_select(int idx, const ConvKP& p, ConvKernelInfo* info, size_t* lds_bytes);
 // conv_tconv.hip: streaming backward-data kernel of the first stride-2 convolution (dZ 64 channels -> dX 32 channels)
 bool od_tconv_small_supported(const od_conv_desc* d);
 int od_tconv_small_launch(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, const char** kernel_name, bool dry_run);

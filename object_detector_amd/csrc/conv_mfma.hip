@@ -413,37 +413,18 @@ struct TileCfg {
   }
 
 //                   BM   BN  BK ST WM WN minwaves/SIMD
+// Only what pick_cfg / the bn_partials fallback can select (round 3: the 22 table configs, the LDS-window kernels and the
+// persistent window kernel that never won a layer are gone -- profiles/r01/conv_cfg_sweep.txt, profiles/r02/spec64_sweep.txt
+// record what they measured).
 const TileCfg g_cfgs[] = {
-    OD_CFG_G(128, 128, 64, 2, 2, 2, 2),  // 0: round-1 baseline geometry (64 KiB, 2 WG/CU)
+    OD_CFG_G(128, 128, 64, 2, 2, 2, 2),  // 0: generic geometry (any Cin % 8 == 0; 64 KiB, 2 WG/CU)
     OD_CFG_G(128, 64, 64, 2, 2, 2, 2),   // 1
     OD_CFG_G(64, 128, 64, 2, 2, 2, 2),   // 2
     OD_CFG_G(64, 64, 64, 2, 2, 2, 2),    // 3
-    OD_CFG(128, 128, 64, 3, 2, 2, 1),    // 4: 96 KiB ring, 1 WG/CU
-    OD_CFG(128, 128, 32, 4, 2, 2, 2),    // 5: 64 KiB ring, 2 WG/CU
-    OD_CFG(128, 128, 32, 3, 2, 2, 2),    // 6: 48 KiB ring, 3 WG/CU
-    OD_CFG(256, 128, 32, 3, 2, 2, 2),    // 7: wave tile 128x64, 72 KiB, 2 WG/CU
-    OD_CFG(256, 128, 64, 3, 4, 2, 2),    // 8: 8 waves, 144 KiB, 1 WG/CU
-    OD_CFG(128, 256, 64, 3, 2, 4, 2),    // 9: 8 waves, 144 KiB
-    OD_CFG(128, 64, 32, 4, 2, 2, 2),     // 10
-    OD_CFG(64, 128, 32, 4, 2, 2, 2),     // 11
-    OD_CFG(64, 64, 32, 4, 2, 2, 2),      // 12
-    OD_CFG_S(128, 128, 64, 2, 2, 2, 4),  // 13: 4 MFMA waves + 4 DMA waves, 64 KiB, 2 WG/CU
-    OD_CFG_S(128, 128, 64, 3, 2, 2, 2),  // 14: same, 3-deep ring (96 KiB, 1 WG/CU)
-    OD_CFG_S(256, 128, 64, 2, 2, 2, 2),  // 15: MFMA wave tile 128x64, 96 KiB, 1 WG/CU
-    OD_CFG_S(256, 128, 64, 3, 2, 2, 2),  // 16: 144 KiB
-    OD_CFG_S(64, 128, 64, 2, 2, 2, 4),   // 17: small-M layers
-    OD_CFG_S2(128, 128, 64, 2, 2, 2, 4), // 18: register-staged loaders, 2 WG/CU
-    OD_CFG_S2(64, 128, 64, 2, 2, 2, 4),  // 19
-    OD_CFG_S2(256, 128, 64, 2, 2, 2, 2), // 20: 96 KiB, 1 WG/CU
-    OD_CFG(256, 256, 64, 2, 4, 4, 4),    // 21: 16 waves (4 per SIMD, wave tile 64x64), 128 KiB, 1 WG/CU
-    OD_CFG(256, 256, 32, 4, 4, 4, 4),    // 22: same, 32-deep steps, 4-deep ring
-    OD_CFG(256, 256, 32, 3, 4, 4, 4),    // 23: 3-deep ring (96 KiB)
-    OD_CFG(64, 64, 64, 4, 2, 2, 2),      // 24: deep rings for the short-K 1x1 layers (cold L2: latency, not bandwidth)
-    OD_CFG(64, 128, 64, 3, 2, 2, 2),     // 25: 72 KiB, 2 WG/CU
-    OD_CFG(64, 128, 64, 4, 2, 2, 2),     // 26: 96 KiB, 1 WG/CU
-    OD_CFG_S(64, 128, 64, 3, 2, 2, 4),   // 27: specialised, 72 KiB
-    OD_CFG_S(64, 128, 64, 4, 2, 2, 2),   // 28: specialised, 96 KiB
-    OD_CFG(128, 128, 64, 4, 2, 2, 1),    // 29: 128 KiB
+    OD_CFG_S(128, 128, 64, 2, 2, 2, 4),  // 4: 4 MFMA waves + 4 DMA waves, 64 KiB, 2 WG/CU
+    OD_CFG_S(128, 128, 64, 3, 2, 2, 2),  // 5: same, 3-deep ring (96 KiB, 1 WG/CU): few tiles, long K
+    OD_CFG(64, 64, 64, 4, 2, 2, 2),      // 6: deep ring for the short-K 1x1 layers (cold L2: latency, not bandwidth)
+    OD_CFG_S(64, 128, 64, 3, 2, 2, 4),   // 7: specialised 64 x 128, 72 KiB: small-M layers
 };
 constexpr int kNumCfgs = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
@@ -456,10 +437,10 @@ const void* stats_kernel(int cfg, int variant) {
     case 1: return variant == 0 ? OD_ST(128, 64, 64, 2, 2, 2, 1, 2, true, 0) : variant == 1 ? OD_ST(128, 64, 64, 2, 2, 2, 3, 2, true, 0) : OD_ST(128, 64, 64, 2, 2, 2, 3, 2, false, 0);
     case 2: return variant == 0 ? OD_ST(64, 128, 64, 2, 2, 2, 1, 2, true, 0) : variant == 1 ? OD_ST(64, 128, 64, 2, 2, 2, 3, 2, true, 0) : OD_ST(64, 128, 64, 2, 2, 2, 3, 2, false, 0);
     case 3: return variant == 0 ? OD_ST(64, 64, 64, 2, 2, 2, 1, 2, true, 0) : variant == 1 ? OD_ST(64, 64, 64, 2, 2, 2, 3, 2, true, 0) : OD_ST(64, 64, 64, 2, 2, 2, 3, 2, false, 0);
-    case 13: return variant == 0 ? OD_ST(128, 128, 64, 2, 2, 2, 1, 4, true, 1) : variant == 1 ? OD_ST(128, 128, 64, 2, 2, 2, 3, 4, true, 1) : nullptr;
-    case 14: return variant == 0 ? OD_ST(128, 128, 64, 3, 2, 2, 1, 2, true, 1) : variant == 1 ? OD_ST(128, 128, 64, 3, 2, 2, 3, 2, true, 1) : nullptr;
-    case 24: return variant == 0 ? OD_ST(64, 64, 64, 4, 2, 2, 1, 2, true, 0) : variant == 1 ? OD_ST(64, 64, 64, 4, 2, 2, 3, 2, true, 0) : nullptr;
-    case 27: return variant == 0 ? OD_ST(64, 128, 64, 3, 2, 2, 1, 4, true, 1) : variant == 1 ? OD_ST(64, 128, 64, 3, 2, 2, 3, 4, true, 1) : nullptr;
+    case 4: return variant == 0 ? OD_ST(128, 128, 64, 2, 2, 2, 1, 4, true, 1) : variant == 1 ? OD_ST(128, 128, 64, 2, 2, 2, 3, 4, true, 1) : nullptr;
+    case 5: return variant == 0 ? OD_ST(128, 128, 64, 3, 2, 2, 1, 2, true, 1) : variant == 1 ? OD_ST(128, 128, 64, 3, 2, 2, 3, 2, true, 1) : nullptr;
+    case 6: return variant == 0 ? OD_ST(64, 64, 64, 4, 2, 2, 1, 2, true, 0) : variant == 1 ? OD_ST(64, 64, 64, 4, 2, 2, 3, 2, true, 0) : nullptr;
+    case 7: return variant == 0 ? OD_ST(64, 128, 64, 3, 2, 2, 1, 4, true, 1) : variant == 1 ? OD_ST(64, 128, 64, 3, 2, 2, 3, 4, true, 1) : nullptr;
     default: return nullptr;
   }
 }
@@ -475,14 +456,14 @@ int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize, bool e8_ok,
     if (!spec_ok) return 3;
     // small-M layers, measured IN the network (scripts/sweep_net_cfg.py, profiles/r01/conv_innet_sweep.txt): their input
     // was just written by the previous kernel, every first touch misses L2, so ring depth matters more than in a
-    // back-to-back microbenchmark -- 3-deep specialised 64x128 (27) for M <= 16 k, 4-deep 64x64 (24) for long-K 1x1 at M <= 4 k.
+    // back-to-back microbenchmark -- 3-deep specialised 64x128 (7) for M <= 16 k, 4-deep 64x64 (6) for long-K 1x1 at M <= 4 k.
     // (Round 2 tried a SPECIALISED 64 x 64 tile -- 4 MFMA + 4 DMA waves -- for these short-K layers: slower than the plain
     // one on every 1x1 shape, 15.9 vs 13.0 us on s3.a; profiles/r02/spec64_sweep.txt.)
-    if (M <= 4096) return (M >= 2048 && Cin >= 512) ? 24 : 3;
-    if (M <= 16384) return 27;
+    if (M <= 4096) return (M >= 2048 && Cin >= 512) ? 6 : 3;
+    if (M <= 16384) return 7;
     if (Cout < 256) return 3;
     // wide 1x1 (neck laterals): fall through to the 128x128 / 8-wave comparison below
-    if (t128 < cus) return 13;
+    if (t128 < cus) return 4;
   }
   if (!spec_ok) return t128 >= 2L * cus ? 0 : 2;
   if (throughput && e8_ok && ksize == 3 && Cout >= 192 && M >= 2048) {
@@ -491,7 +472,7 @@ int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize, bool e8_ok,
     // L2->LDS bytes per flop) then also takes the stage-4 / stage-5 layers (profiles/r01/inflight_sweep.txt: +4.5 % img/s)
     const int nk = od_ceil_div(ksize * ksize * Cin, 64);
     double best = t128 >= cus ? t128 * (7.5 + 1.07 * nk) * 0.5 : t128 * (10.0 + 0.55 * nk);
-    int pick = t128 >= cus ? 13 : (Cout <= 256 ? 27 : 14);
+    int pick = t128 >= cus ? 4 : (Cout <= 256 ? 7 : 5);
     for (int i = 0; i < od_conv_8ph_num_cfgs(); ++i) {
       const int mt = 8 - i, bm = 32 * mt;
       const long tiles = (long)od_ceil_div(M, bm) * od_ceil_div(Cout, 256);
@@ -499,7 +480,7 @@ int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize, bool e8_ok,
       const double c = (double)tiles * (13.0 + 1.78 * nk * (0.5 + 0.0625 * mt));
       if (c < 0.95 * best) {
         best = c / 0.95;
-        pick = kNumCfgs + od_conv_win_num_cfgs() + 1 + i;
+        pick = kNumCfgs + i;
       }
     }
     return pick;
@@ -511,19 +492,19 @@ int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize, bool e8_ok,
     const int nk = od_ceil_div(ksize * ksize * Cin, 64);
     const double c13 = (double)od_ceil_div((int)t128, 2 * cus) * (7.5 + 1.07 * nk);
     double best = 0.93 * c13;
-    int pick = 13;
+    int pick = 4;
     for (int i = 0; e8_ok && i < od_conv_8ph_num_cfgs(); ++i) {
       const int mt = 8 - i, bm = 32 * mt;
       const long tiles = (long)od_ceil_div(M, bm) * od_ceil_div(Cout, 256);
       const double c = (double)((tiles + cus - 1) / cus) * (13.0 + 1.78 * nk * (0.5 + 0.0625 * mt));
       if (c < best) {
         best = c;
-        pick = kNumCfgs + od_conv_win_num_cfgs() + 1 + i;
+        pick = kNumCfgs + i;
       }
     }
     return pick;
   }
-  if (Cout <= 256) return M < 2048 ? 3 : 27;       // few, narrow tiles (neck / prediction module on the coarse levels)
+  if (Cout <= 256) return M < 2048 ? 3 : 7;       // few, narrow tiles (neck / prediction module on the coarse levels)
   // few tiles, long K.  Up to half a round of 128 x 128 tiles (backward-data of stage 5: M = 3200, Cout = 512, K = 9216) the
   // 64-row specialised tile doubles the workgroups: 55.6 vs 78.8 us (profiles/r02/dgrad_cfg_sweep.txt); above that one
   // deep-ring workgroup per CU
@@ -533,12 +514,12 @@ int pick_cfg(const od_ctx* ctx, int M, int Cin, int Cout, int ksize, bool e8_ok,
     last = e ? atoi(e) : -1;
   }
   if (last >= 0) return last;
-  return (M >= 2048 && 2 * t128 <= cus) ? 27 : 14;  // (batch-1 maps keep their split-K plan on 14)
+  return (M >= 2048 && 2 * t128 <= cus) ? 7 : 5;  // (batch-1 maps keep their split-K plan on 5)
 }
 
 }  // namespace
 
-extern "C" int od_conv_num_tile_cfgs(void) { return kNumCfgs + od_conv_win_num_cfgs() + 1 + od_conv_8ph_num_cfgs(); }
+extern "C" int od_conv_num_tile_cfgs(void) { return kNumCfgs + od_conv_8ph_num_cfgs(); }
 
 extern "C" int od_conv_weight_dims(int cout, int cin, int ksize, int* cout_pad, int* kpad) {
   OD_REQUIRE(cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), "od_conv_weight_dims: bad dims");
@@ -667,19 +648,15 @@ static int od_conv2d_fwd_main(od_ctx* ctx, const od_conv_desc* d, hipStream_t st
     const int var = d->ksize == 1 ? 0 : ((d->Cin % g_cfgs[cfg].BK) == 0 ? 1 : 2);
     if (!stats_kernel(cfg, var)) {  // same tile shape without the feature the table lacks, else the generic 128 x 128 / 64 x 128
       const int bm = g_cfgs[cfg].BM, bn = g_cfgs[cfg].BN;
-      cfg = (d->Cin % 64 == 0) ? ((bm >= 128 && bn >= 128) ? 13 : (bn >= 128 ? 27 : 3)) : ((bm >= 128 && bn >= 128) ? 0 : (bn >= 128 ? 2 : (bm >= 128 ? 1 : 3)));
+      cfg = (d->Cin % 64 == 0) ? ((bm >= 128 && bn >= 128) ? 4 : (bn >= 128 ? 7 : 3)) : ((bm >= 128 && bn >= 128) ? 0 : (bn >= 128 ? 2 : (bm >= 128 ? 1 : 3)));
     }
   }
-  const int cfg_pw = kNumCfgs + od_conv_win_num_cfgs(), cfg_e8 = cfg_pw + 1;
+  const int cfg_e8 = kNumCfgs;
   OD_REQUIRE(cfg < cfg_e8 + od_conv_8ph_num_cfgs(), "od_conv2d_fwd: tile_cfg %d out of range", cfg);
-  const bool use_pw = cfg == cfg_pw;
   const bool use_e8 = cfg >= cfg_e8;
-  const bool use_win_ = cfg >= kNumCfgs && cfg < cfg_e8;
-  OD_REQUIRE(!(want_stats && (use_e8 || use_win_)),
-             "od_conv2d_fwd: bn_partials is supported by the table kernels only (tile_cfg %d)", cfg);
-  const bool use_win = cfg >= kNumCfgs && !use_pw && !use_e8;
-  OD_REQUIRE(!tconv || !(use_win || use_pw || use_e8), "od_conv2d_fwd: transposed mode runs on the table kernels only (tile_cfg %d)", cfg);
-  TileCfg tc = g_cfgs[(use_win || use_pw || use_e8) ? 0 : cfg];
+  OD_REQUIRE(!(want_stats && use_e8), "od_conv2d_fwd: bn_partials is supported by the table kernels only (tile_cfg %d)", cfg);
+  OD_REQUIRE(!tconv || !use_e8, "od_conv2d_fwd: transposed mode runs on the table kernels only (tile_cfg %d)", cfg);
+  TileCfg tc = g_cfgs[use_e8 ? 0 : cfg];
 
   ConvKP p;
   p.x = (const f16*)d->x;
@@ -729,52 +706,6 @@ static int od_conv2d_fwd_main(od_ctx* ctx, const od_conv_desc* d, hipStream_t st
       dbg = e ? atoi(e) : 0;
     }
     p.dbg = dbg;
-  }
-  if (use_pw) {
-    // persistent wave-specialised window kernel (conv_pw.hip)
-    p.splitk = 1;
-    p.steps_per_split = 0;
-    p.ws = nullptr;
-    ConvKernelInfo ki;
-    size_t lds = 0;
-    int np = 0, grid = 0, ntt = 0;
-    OD_REQUIRE(d->ksize == 3, "od_conv2d_fwd: tile_cfg %d is a 3x3 window kernel", cfg);
-    if (!od_conv_pw_select(p, ctx->num_cu, &ki, &lds, &np, &grid, &ntt)) {
-      od_set_error("od_conv2d_fwd: persistent window kernel does not support this shape (stride 1, Cin %% 64 == 0, W = %d)",
-                   d->W);
-      return OD_ERR_INVALID;
-    }
-    p.mtiles = od_ceil_div(M, ki.BM);
-    p.ntiles = od_ceil_div(d->Cout, ki.BN);
-    if (kernel_name) *kernel_name = ki.name;
-    if (dry_run) return OD_OK;
-    if (int rc = od_ensure_lds(ctx, ki.fn, lds)) return rc;
-    void* wargs[] = {&p, &np, &ntt};
-    OD_CHECK_HIP(hipLaunchKernel(ki.fn, dim3(grid), dim3(ki.threads), wargs, lds, stream));
-    return OD_OK;
-  }
-  if (use_win) {
-    // LDS-window direct 3x3 (conv_win.hip); never split-K
-    p.splitk = 1;
-    p.steps_per_split = 0;
-    p.ws = nullptr;
-    ConvKernelInfo ki;
-    size_t lds = 0;
-    OD_REQUIRE(d->ksize == 3, "od_conv2d_fwd: tile_cfg %d is a 3x3 window kernel", cfg);
-    if (!od_conv_win_select(cfg - kNumCfgs, p, &ki, &lds)) {
-      od_set_error("od_conv2d_fwd: window kernel cfg %d does not support this shape (stride 1, Cin %% 64 == 0, W = %d)",
-                   cfg, d->W);
-      return OD_ERR_INVALID;
-    }
-    p.mtiles = od_ceil_div(M, ki.BM);
-    p.ntiles = od_ceil_div(d->Cout, ki.BN);
-    if (kernel_name) *kernel_name = ki.name;
-    if (dry_run) return OD_OK;
-    if (int rc = od_ensure_lds(ctx, ki.fn, lds)) return rc;
-    int np = (ki.BM + 2 * d->W + 2 + 15) / 16;
-    void* wargs[] = {&p, &np};
-    OD_CHECK_HIP(hipLaunchKernel(ki.fn, dim3(p.mtiles * p.ntiles), dim3(ki.threads), wargs, lds, stream));
-    return OD_OK;
   }
   ConvKernelInfo e8;
   if (use_e8) {
@@ -859,7 +790,7 @@ static int od_conv2d_fwd_main(od_ctx* ctx, const od_conv_desc* d, hipStream_t st
   if (want_stats) {
     fn = stats_kernel(cfg, variant);
     if (!fn) {
-      od_set_error("od_conv2d_fwd: tile_cfg %d has no bn_partials instantiation for this layer (have: 0-3, 13, 14, 24, 27)", cfg);
+      od_set_error("od_conv2d_fwd: tile_cfg %d has no bn_partials instantiation for this layer (have: 0-7)", cfg);
       return OD_ERR_INVALID;
     }
   }

@@ -70,6 +70,64 @@ def gather_results(local: dict, world: int) -> dict:
     return out
 
 
+_QUEUE_SETS = {}  # (device index, n) -> [torch.cuda.Stream] that were measured to run concurrently
+
+
+def _streams_overlap(a, b, spin_cycles):
+    """True when a kernel queued on `b` finishes while an earlier, long kernel on `a` is still running (different hardware
+    queues); False when `b`'s kernel had to wait for it (same queue)."""
+    ea, eb = torch.cuda.Event(), torch.cuda.Event()
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(spin_cycles)
+        ea.record()
+    with torch.cuda.stream(b):
+        torch.cuda._sleep(1)
+        eb.record()
+    eb.synchronize()
+    free = not ea.query()
+    ea.synchronize()
+    return free
+
+
+def stream_queue_sets(device, n, candidates=6, seed_streams=()):
+    """n streams of `device` that overlap pairwise, chosen greedily from `candidates` fresh streams by the probe above
+    (about 2 ms per pair, a few dozen ms once per process); cached.  Falls back to creation order when the probe cannot
+    tell streams apart (e.g. a runtime that serialises everything)."""
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), n)
+    if key in _QUEUE_SETS:
+        return _QUEUE_SETS[key]
+    with torch.cuda.device(device):
+        cands = list(seed_streams) + [torch.cuda.Stream(device=device) for _ in range(max(candidates, n) - len(seed_streams))]
+        for c in cands:  # every stream's first launch (queue creation) happens outside the probes
+            with torch.cuda.stream(c):
+                torch.cuda._sleep(1000)
+        torch.cuda.synchronize(device)
+        # spin length: ~2 ms of a kernel that does nothing but read the clock (calibrated, the tick rate is not assumed)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(cands[0]):
+            torch.cuda._sleep(1000)  # first launch: module load
+            e0.record()
+            torch.cuda._sleep(200000)
+            e1.record()
+        e1.synchronize()
+        per_ms = 200000 / max(e0.elapsed_time(e1), 1e-3)
+        spin = int(max(1000, 2.0 * per_ms))
+        chosen = []
+        for c in cands:
+            if len(chosen) == n:
+                break
+            if all(_streams_overlap(q, c, spin) and _streams_overlap(c, q, spin) for q in chosen):
+                chosen.append(c)
+        for c in cands:  # not enough distinguishable queues: take the rest in creation order
+            if len(chosen) == n:
+                break
+            if c not in chosen:
+                chosen.append(c)
+    _QUEUE_SETS[key] = chosen
+    return chosen
+
+
 class _Pipeline:
     """One batch in flight: its own activation buffers (Net), post-processing buffers and HIP stream."""
 
@@ -157,7 +215,7 @@ class ObjectDetector:
         """Queue one batch on the next pipeline's stream and return its ticket.  Never blocks the host: a pipeline's new
         batch is stream-ordered behind its previous one (whose results it overwrites -- collect() them first)."""
         if not self._calibrated:
-            self._calibrate_streams(x_u8, conf_threshold)
+            self._pick_streams()
         i = self._next
         self._next = (i + 1) % len(self._pipes)
         p = self._pipes[i]
@@ -171,35 +229,16 @@ class ObjectDetector:
         x_u8.record_stream(p.stream)
         return i
 
-    def _calibrate_streams(self, x_u8, conf_threshold):
-        """HIP maps streams onto a few hardware queues (4 by default) in creation order, and kernels of two streams on
-        the same queue do not overlap: which of a set of fresh streams collide -- with each other or with the queue the
-        caller's stream sits on -- depends on how many streams the process created before (measured: 15.9 k instead of
-        18.8 k images/s with 1-2 foreign streams created first).  So: one more candidate stream than pipelines, and the
-        combination that is fastest on a few real steps wins.  ~60 ms once per detector."""
-        import itertools
-        import time
+    def _pick_streams(self):
+        """One stream per pipeline, on DIFFERENT hardware queues.  HIP deals streams onto a few hardware queues (4 by
+        default) in creation order, and kernels of two streams that share a queue never overlap: with 1-2 foreign streams
+        created first the same code ran at 15.9 k instead of 18.8 k images/s.  Instead of timing real steps on every stream
+        combination (rounds 1-2), the queue map is MEASURED once per process and device with a probe that does no real work
+        (stream_queue_sets) and cached; every detector of the process takes its streams from that set."""
         self._calibrated = True
-        n = len(self._pipes)
-        cands = [p.stream for p in self._pipes] + [torch.cuda.Stream(device=self.device) for _ in range(max(1, 5 - n))]
-
-        def run(steps):
-            for _ in range(steps):
-                self.submit(x_u8, conf_threshold)
-            torch.cuda.synchronize(self.device)
-
-        best, best_t = None, None
-        for combo in itertools.combinations(range(len(cands)), n):
-            for p, ci in zip(self._pipes, combo):
-                p.stream = cands[ci]
-            run(n)  # warm-up (first touch of every buffer, kernel attribute calls)
-            t0 = time.perf_counter()
-            run(2 * n)
-            dt = time.perf_counter() - t0
-            if best_t is None or dt < best_t:
-                best, best_t = combo, dt
-        for p, ci in zip(self._pipes, best):
-            p.stream = cands[ci]
+        sts = stream_queue_sets(self.device, len(self._pipes), seed_streams=[p.stream for p in self._pipes])
+        for p, st in zip(self._pipes, sts):
+            p.stream = st
         self._next = 0
 
     def collect(self, ticket: int):

@@ -159,7 +159,14 @@ class Net:
         # TIMING ABLATION ONLY (results become garbage): drop ops whose name matches a prefix*suffix pattern, to measure what a
         # group of layers costs inside the running pipeline (scripts/dev/exp_ablate.sh); never set in tests / bench lines
         abl = [q.partition("*") for q in filter(None, os.environ.get("OD_ABLATE_OPS", "").split(","))]
+        self.ablated = bool(abl)
+        if abl and os.environ.get("OD_ALLOW_ABLATION") != "1":
+            # a leaked variable must not silently drop layers from a product plan: the dev scripts set both
+            raise _lib.OdError("OD_ABLATE_OPS is set (a TIMING ablation: it drops layers, results are garbage) without "
+                               "OD_ALLOW_ABLATION=1; unset it")
         if abl:
+            import warnings
+            warnings.warn(f"OD_ABLATE_OPS={os.environ['OD_ABLATE_OPS']!r}: layers dropped from the plan, outputs are garbage")
             seen, occ = {}, []
             for inf in self.op_info:  # "name#k" = the k-th launch of a layer that runs once per pyramid level
                 occ.append(f'{inf["name"]}#{seen.get(inf["name"], 0)}')

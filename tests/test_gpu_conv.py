@@ -28,9 +28,8 @@ def _ref(x, w, scale, bias, stride, act, alpha, res=None, up2=False):
     return y
 
 
-NIG, NWIN = 30, 12   # implicit-GEMM tile configs 0..29, LDS-window configs 30..41, persistent window kernel 42
-NPW = NIG + NWIN
-SPEC0 = 13            # first wave-specialised implicit-GEMM config
+NIG = 8               # implicit-GEMM table configs 0..7 (what pick_cfg can select: 0-3 generic, 4/5/7 wave-specialised, 6 deep ring)
+SPEC = (4, 5, 7)      # the wave-specialised ones (tap-uniform only: Cin % 64 == 0)
 
 CASES = [
     # B, H, W, Cin, Cout, k, stride, act, res, cfg
@@ -41,23 +40,14 @@ CASES = [
     (2, 12, 20, 256, 256, 3, 1, "elu", "up2", -1),      # neck lateral-style, non-square
     (2, 10, 10, 512, 1024, 3, 1, "leaky", "same", -1),  # long K
     (1, 4, 4, 8, 8, 3, 1, None, "none", -1),            # tiny everything: Cin=8, single partial tile
-    (2, 16, 16, 32, 64, 3, 2, "leaky", "none", 5),      # Cin=32 is tap-uniform at BK=32
-    (2, 9, 9, 40, 72, 1, 1, "leaky", "none", 5),        # 1x1 channel tail (Cin=40) masked per lane
-    (1, 6, 6, 24, 16, 3, 1, "leaky", "none", 3),        # generic 3x3 (Cin=24) on a legacy config
+    (2, 16, 16, 32, 64, 3, 2, "leaky", "none", 1),      # Cin=32: the generic (per-lane tap) 3x3 variant
+    (2, 9, 9, 40, 72, 1, 1, "leaky", "none", 2),        # 1x1 channel tail (Cin=40) masked per lane
+    (1, 6, 6, 24, 16, 3, 1, "leaky", "none", 3),        # generic 3x3 (Cin=24)
 ]
-CASES += [(2, 12, 12, 64, 128, 3, 1, "leaky", "same", c) for c in range(NIG + NWIN)]          # every config
-CASES += [(3, 10, 10, 128, 64, 1, 1, "elu", "none", c) for c in range(4, NIG)]                 # 1x1 on every igemm config
-CASES += [(2, 10, 10, 512, 256, 3, 1, "leaky", "same", c) for c in range(SPEC0, NIG)]          # specialised, long K
-CASES += [(3, 10, 10, 256, 320, 3, 1, "elu", "none", c) for c in range(NIG, NIG + NWIN)]      # window: slice changes, ragged M/N
-CASES += [(1, 40, 40, 128, 256, 3, 1, "leaky", "same", c) for c in (NIG, NIG + 6, NIG + 8, NIG + 10)]  # W = 40
-CASES += [(2, 12, 12, 64, 128, 3, 1, "leaky", "same", NPW),          # persistent window kernel
-          (3, 10, 10, 256, 320, 3, 1, "elu", "none", NPW),           # 4 slices, ragged M and N
-          (1, 40, 40, 128, 256, 3, 1, "leaky", "same", NPW),
-          (2, 20, 20, 512, 128, 3, 1, "leaky", "up2", NPW),
-          (1, 3, 5, 64, 64, 3, 1, None, "none", NPW),
-          (9, 80, 80, 64, 256, 3, 1, "leaky", "same", NPW),          # 450 tiles > 256 CUs: workgroups walk 2 tiles
-          (5, 40, 40, 128, 1024, 3, 1, "leaky", "none", NPW)]        # 8 n-tiles, 2 slices
-NE8, NE8N = NPW + 1, 4   # 8-wave BM x 256 kernels (conv_8ph.hip): BM = 256, 224, 192, 160
+CASES += [(2, 12, 12, 64, 128, 3, 1, "leaky", "same", c) for c in range(NIG)]                  # every config
+CASES += [(3, 10, 10, 128, 64, 1, 1, "elu", "none", c) for c in range(NIG)]                    # 1x1 on every config
+CASES += [(2, 10, 10, 512, 256, 3, 1, "leaky", "same", c) for c in SPEC + (6,)]                # specialised / deep ring, long K
+NE8, NE8N = NIG, 4   # 8-wave BM x 256 kernels (conv_8ph.hip): BM = 256, 224, 192, 160
 for _c in range(NE8, NE8 + NE8N):
     CASES += [(2, 12, 12, 64, 128, 3, 1, "leaky", "same", _c),        # 9 K tiles, two m-tiles
               (3, 10, 10, 256, 320, 3, 1, "elu", "none", _c),         # two n-tiles, ragged M and N
@@ -76,13 +66,11 @@ CASES += [(2, 16, 32, 64, 32, 3, 1, "leaky", "none", -1),     # 64 -> 32 (backwa
           (3, 40, 64, 32, 64, 3, 2, "leaky", "none", -1),
           (5, 44, 80, 64, 32, 3, 1, None, "none", -1),        # 55 tiles per image, 275 tiles: several ring turns per workgroup
           (32, 160, 160, 32, 64, 3, 1, "leaky", "none", -1)]  # the training step's own shape (12 800 tiles)
-CASES += [(2, 20, 20, 512, 128, 3, 1, "leaky", "up2", NIG + 3),                                 # 8 slices
-          (1, 3, 5, 64, 64, 3, 1, None, "none", NIG + 1)]                                       # map smaller than a tile
 
 
 def test_config_table_size(cuda):
     from object_detector_amd import _lib
-    assert _lib.load().od_conv_num_tile_cfgs() == NIG + NWIN + 1 + NE8N
+    assert _lib.load().od_conv_num_tile_cfgs() == NIG + NE8N
 
 
 @pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
@@ -164,7 +152,7 @@ for _c in range(NE8, NE8 + NE8N):  # every BM of the 8-wave kernel: the second l
                  (3, 9, 7, 192, 256, 3, 1, "elu", "same", "elu", _c),         # ragged last tile (189 pixels), ELU on both
                  (2, 10, 10, 512, 256, 1, 1, "leaky", "up2", None, _c)]       # 1x1 first layer, upsampled residual, linear second
 PW_CASES += [(2, 20, 20, 128, 256, 3, 1, "leaky", "same", "leaky", -1),        # library's choice: fused or two launches
-             (2, 20, 20, 128, 256, 3, 1, "leaky", "same", "leaky", 13),       # table kernel: always two launches
+             (2, 20, 20, 128, 256, 3, 1, "leaky", "same", "leaky", 4),        # table kernel: always two launches
              (2, 12, 12, 64, 128, 3, 1, "leaky", "same", "leaky", NE8),       # Cout != 256: two launches
              (8, 40, 40, 128, 256, 3, 1, "leaky", "same", "leaky", -2)]       # throughput-mode choice at a multi-tile size
 
@@ -214,15 +202,15 @@ def test_conv_with_consuming_pointwise_layer(cuda, case):
 
 @pytest.mark.parametrize("case", [
     # B, H, W, Cin, Cout, k, stride, act, res, cfg, splitk
-    (1, 10, 10, 512, 1024, 3, 1, "leaky", "same", 13, 0),   # batch-1 stage-5 shape, library-chosen split
+    (1, 10, 10, 512, 1024, 3, 1, "leaky", "same", 5, 0),    # batch-1 stage-5 shape, library-chosen split
     (1, 10, 10, 512, 1024, 3, 1, "leaky", "same", 0, 6),
-    (1, 20, 20, 512, 256, 1, 1, "elu", "up2", 17, 4),       # 1x1, split over channels
+    (1, 20, 20, 512, 256, 1, 1, "elu", "up2", 7, 4),        # 1x1, split over channels
     (1, 20, 20, 256, 512, 3, 2, "leaky", "none", 2, 0),     # stride 2
     (1, 10, 10, 256, 208, 3, 1, None, "none", 3, 5),        # ragged Cout, generic-capable config
     (2, 6, 6, 40, 72, 3, 1, "leaky", "same", 3, 3),         # non-uniform taps (Cin = 40) + split
-    (1, 10, 10, 512, 1024, 3, 1, "leaky", "same", NIG + 13, 6),   # 8-wave kernel, 12 K tiles per split
-    (2, 10, 10, 512, 304, 3, 1, "elu", "none", NIG + 15, 5),      # BM = 192, uneven split (72 tiles / 5)
-    (1, 20, 20, 512, 256, 1, 1, "elu", "up2", NIG + 14, 4),       # 1x1, 2 K tiles per split
+    (1, 10, 10, 512, 1024, 3, 1, "leaky", "same", NE8, 6),   # 8-wave kernel, 12 K tiles per split
+    (2, 10, 10, 512, 304, 3, 1, "elu", "none", NE8 + 2, 5),      # BM = 192, uneven split (72 tiles / 5)
+    (1, 20, 20, 512, 256, 1, 1, "elu", "up2", NE8 + 1, 4),       # 1x1, 2 K tiles per split
 ], ids=str)
 def test_conv_split_k(cuda, case):
     """split-K path: per-split f32 slabs + finish kernel summing them in a fixed order (bit-reproducible)."""
