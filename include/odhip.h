@@ -220,6 +220,25 @@ int od_nms(od_ctx* ctx, const float* boxes, const uint64_t* keys, const int32_t*
 int od_gather_detections(od_ctx* ctx, const float* conf, const float* boxes, const int32_t* keep_flat,
                          const int32_t* keep_count, int B, int P, int NC, int max_det, float* out, void* stream);
 
+/* K5-K8 as ONE call, the path `predict` runs (reference voc_validate.py:27; docs/MODEL.md:54-58,78-82): pred -> decoded boxes,
+ * the exact top-K key set, class-aware NMS kept indices -- five launches, the confidence tensor is never materialised
+ * (one pass over pred computes the confidences on chip, their first-digit histogram and one max per prior; the second pass
+ * recomputes only the priors that can hold a top-K candidate).  Results are bit-identical to od_head_postprocess ->
+ * od_topk_scores -> od_nms on the same pred (keys come back SORTED descending here, unused slots 0).
+ *   conf: optional dense f32 [B,P,NC] output (NULL in the product path);  workspace: od_detect_workspace_bytes, zeroed once
+ *   with od_detect_workspace_init (every call leaves it ready for the next);  nms_workspace: od_nms_workspace_bytes(B, K).
+ *   P even, NC <= 90, K <= 1024. */
+size_t od_detect_workspace_bytes(int B, int P, int NC, int K);
+int od_detect_workspace_init(od_ctx* ctx, void* workspace, size_t workspace_bytes, int B, int P, int NC, void* stream);
+int od_detect(od_ctx* ctx, const float* pred, const float* priors, int B, int P, int NC, float loc_scale, int clip,
+              float conf_threshold, int K, float iou_threshold, int strict, int max_det, float* boxes, float* conf,
+              uint64_t* keys, int32_t* counts, int32_t* keep_flat, int32_t* keep_count, void* workspace,
+              size_t workspace_bytes, void* nms_workspace, size_t nms_workspace_bytes, void* stream);
+/* od_gather_detections without a confidence tensor: the kept detections' confidences are recomputed from pred (same code,
+ * same bits). */
+int od_gather_detections_pred(od_ctx* ctx, const float* pred, const float* boxes, const int32_t* keep_flat,
+                              const int32_t* keep_count, int B, int P, int NC, int max_det, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K9: prior-box assignment + target encoding = od.pb.encode_truth (reference check_assign.py:21,25-27).
  *   priors f32 [P,4]; gt_boxes f32 [B,Gmax,4] corner form, normalised; gt_classes i32 [B,Gmax]; gt_counts i32 [B]

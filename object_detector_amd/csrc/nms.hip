@@ -9,7 +9,7 @@
 //          step), kept rows OR their mask rows into the running `removed` words, 16 LDS reads in flight per lane
 // The IoU predicate is division-free f32 arithmetic in a fixed order; this TU is compiled with -ffp-contract=off so
 // it is bit-identical to numpy's (oracle/nms.py), which is what makes the kept-index output bit-exact.
-#include "common.h"
+#include "post_common.h"
 
 namespace {
 
@@ -193,6 +193,36 @@ NmsLayout nms_layout(int B, int KP) {
 
 }  // namespace
 
+void od_nms_sorted_buffers(void* nms_workspace, int B, int K, unsigned long long** skeys, f32x4** sbox, int** scls, int* KP) {
+  const int kp = next_pow2(K);
+  const NmsLayout l = nms_layout(B, kp);
+  char* ws = (char*)nms_workspace;
+  *skeys = (unsigned long long*)(ws + l.skeys);
+  *sbox = (f32x4*)(ws + l.sbox);
+  *scls = (int*)(ws + l.scls);
+  *KP = kp;
+}
+
+int od_nms_mask_scan_launch(od_ctx* ctx, void* nms_workspace, const int32_t* counts, int B, int K, float iou_threshold,
+                            int strict, int max_det, int32_t* keep_flat, int32_t* keep_count, hipStream_t s) {
+  const int KP = next_pow2(K), W = KP / 64;
+  const NmsLayout l = nms_layout(B, KP);
+  char* ws = (char*)nms_workspace;
+  u64* skeys = (u64*)(ws + l.skeys);
+  f32x4* sbox = (f32x4*)(ws + l.sbox);
+  int* scls = (int*)(ws + l.scls);
+  u64* mask = (u64*)(ws + l.mask);
+  hipLaunchKernelGGL(od_nms_mask, dim3(W, B), dim3(1024), (size_t)KP * 20, s, sbox, scls, counts, KP, W, iou_threshold,
+                     strict, mask);
+  OD_CHECK_LAUNCH();
+  const size_t scan_lds = (size_t)KP * W * 8 + 16 * 8;
+  if (int rc = od_ensure_lds(ctx, (const void*)&od_nms_scan, scan_lds)) return rc;
+  hipLaunchKernelGGL(od_nms_scan, dim3(B), dim3(256), scan_lds, s, mask, skeys, counts, KP, W, max_det, keep_flat,
+                     keep_count);
+  OD_CHECK_LAUNCH();
+  return OD_OK;
+}
+
 extern "C" size_t od_nms_workspace_bytes(int B, int K) {
   if (B <= 0 || K <= 0 || K > 1024) return 0;
   return nms_layout(B, next_pow2(K)).total;
@@ -204,7 +234,7 @@ extern "C" int od_nms(od_ctx* ctx, const float* boxes, const uint64_t* keys, con
   OD_REQUIRE(ctx && boxes && keys && counts && keep_flat && keep_count && workspace, "od_nms: null argument");
   OD_REQUIRE(B > 0 && B <= 65535 && P > 0 && NC > 0 && K > 0 && K <= 1024 && max_det > 0,
              "od_nms: bad dims (K <= 1024)");
-  const int KP = next_pow2(K), W = KP / 64;
+  const int KP = next_pow2(K);
   const NmsLayout l = nms_layout(B, KP);
   if (workspace_bytes < l.total) {
     od_set_error("od_nms: workspace %zu < %zu bytes", workspace_bytes, l.total);
@@ -214,18 +244,9 @@ extern "C" int od_nms(od_ctx* ctx, const float* boxes, const uint64_t* keys, con
   u64* skeys = (u64*)(ws + l.skeys);
   f32x4* sbox = (f32x4*)(ws + l.sbox);
   int* scls = (int*)(ws + l.scls);
-  u64* mask = (u64*)(ws + l.mask);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(od_nms_sort, dim3(B), dim3(1024), 0, s, boxes, (const u64*)keys, counts, P, NC, K, KP, skeys, sbox,
                      scls);
   OD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(od_nms_mask, dim3(W, B), dim3(1024), (size_t)KP * 20, s, sbox, scls, counts, KP, W, iou_threshold,
-                     strict, mask);
-  OD_CHECK_LAUNCH();
-  const size_t scan_lds = (size_t)KP * W * 8 + 16 * 8;
-  if (int rc = od_ensure_lds(ctx, (const void*)&od_nms_scan, scan_lds)) return rc;
-  hipLaunchKernelGGL(od_nms_scan, dim3(B), dim3(256), scan_lds, s, mask, skeys, counts, KP, W, max_det, keep_flat,
-                     keep_count);
-  OD_CHECK_LAUNCH();
-  return OD_OK;
+  return od_nms_mask_scan_launch(ctx, workspace, counts, B, K, iou_threshold, strict, max_det, keep_flat, keep_count, s);
 }

@@ -1,25 +1,11 @@
 // K4 (standalone), K5, K6: FPN top-down add, head post-process (objectness x class confidence) and prior-box decode.
 // All HBM-bound elementwise work; rows are staged through LDS so that every global access is a full-line access.
 // Compiled with -ffp-contract=off: the decode arithmetic is the bit-exact f32 sequence of oracle/postprocess.py.
-#include "common.h"
+#include "post_common.h"
 
 namespace {
 
-// boxes = prior + (loc * loc_scale) * [pw, ph, pw, ph], optional clip to [0,1]   (od.pb.decode_locs,
-// reference check_assign.py:27: zero offsets decode to the prior itself)
-__device__ __forceinline__ f32x4 decode_one(f32x4 loc, f32x4 pr, float loc_scale, int clip) {
-  const float pw = pr[2] - pr[0], ph = pr[3] - pr[1];
-  f32x4 o;
-  o[0] = pr[0] + (loc[0] * loc_scale) * pw;
-  o[1] = pr[1] + (loc[1] * loc_scale) * ph;
-  o[2] = pr[2] + (loc[2] * loc_scale) * pw;
-  o[3] = pr[3] + (loc[3] * loc_scale) * ph;
-  if (clip) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = fminf(fmaxf(o[e], 0.f), 1.f);
-  }
-  return o;
-}
+#define decode_one od_decode_one
 
 constexpr int PP_ROWS = 256;  // priors per workgroup
 
@@ -47,17 +33,7 @@ __global__ __launch_bounds__(256) void od_head_post(const float* __restrict__ pr
   __syncthreads();
   if (tid < nrows) {
     const float* row = sin + tid * C;
-    const float obj = 1.f / (1.f + expf(row[0] - row[1]));
-    float mx = row[2];
-    for (int c = 1; c < NC; ++c) mx = fmaxf(mx, row[2 + c]);
-    float s = 0.f;
-    float* orow = sout + tid * NC;
-    for (int c = 0; c < NC; ++c) {
-      const float e = expf(row[2 + c] - mx);
-      orow[c] = e;
-      s += e;
-    }
-    for (int c = 0; c < NC; ++c) orow[c] = obj * (orow[c] / s);
+    od_row_conf(row, NC, sout + tid * NC);
     const long long r = r0 + tid;
     const int p = (int)(r % P);
     const f32x4 loc = {row[2 + NC], row[3 + NC], row[4 + NC], row[5 + NC]};

@@ -10,64 +10,13 @@
 //   4. refine    : one workgroup per image radix-selects the remaining 19 score bits + index bits inside the
 //                  candidate list (LDS histograms; early exit as soon as a bin is taken whole) and appends the winners
 // Output keys are an unordered SET of min(K, #candidates) keys per image (K8 sorts them); unused slots are 0.
-#include "common.h"
+#include "post_common.h"
 
 namespace {
 
-constexpr int NB = 4096;  // histogram bins (first digit = score bits [30:19]; later digits use <= 2048 of them)
-
-struct TopkState {  // per image
-  int d0;           // first digit of the K-th key; -1 = take every candidate (fewer than K exist)
-  int krem;         // how many to take from the d0 bin
-  int nout;         // output slots used
-  int ncand;        // candidate-list length
-};
-
-__device__ __forceinline__ unsigned score_bits(float v, float thr) {
-  return v > thr ? __float_as_uint(v) : 0u;  // positive floats: bit pattern is monotone in value
-}
-
-// Wave-level search of an nbins-bin histogram (in LDS or global) for the bin where the count of elements in HIGHER
-// bins first reaches >= krem.  Returns digit (uniform) and *above = #elements in bins above it.  One wave.
-__device__ __forceinline__ int find_digit(const int* hist, int nbins, int krem, int* above, int* in_bin) {
-  const int lane = threadIdx.x & 63;
-  const int per = nbins / 64;  // bins per lane; lane l owns bins [l*per, (l+1)*per)
-  int s = 0;
-  for (int i = 0; i < per; ++i) s += hist[lane * per + i];
-  // inclusive suffix sum over lanes: suf = sum over lanes >= lane
-  int suf = s;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int o = __shfl_down(suf, off);
-    if (lane + off < 64) suf += o;
-  }
-  const int higher = suf - s;  // elements in lanes above this one
-  const bool mine = higher < krem && suf >= krem;
-  const unsigned long long bal = __ballot(mine);
-  int digit = -1, ab = 0, ib = 0;
-  if (bal) {
-    const int owner = __ffsll((long long)bal) - 1;
-    if (lane == owner) {
-      int run = higher;
-      for (int i = per - 1; i >= 0; --i) {
-        const int c = hist[lane * per + i];
-        if (run + c >= krem) {
-          digit = lane * per + i;
-          ab = run;
-          ib = c;
-          break;
-        }
-        run += c;
-      }
-    }
-    digit = __shfl(digit, owner);
-    ab = __shfl(ab, owner);
-    ib = __shfl(ib, owner);
-  }
-  *above = ab;
-  *in_bin = ib;
-  return digit;
-}
+constexpr int NB = OD_TOPK_NB;
+#define score_bits od_score_bits
+#define find_digit od_find_digit
 
 __global__ __launch_bounds__(256) void od_topk_hist0(const float* __restrict__ conf, int N, float thr,
                                                      int* __restrict__ hist, int chunk) {

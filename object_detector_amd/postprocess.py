@@ -31,7 +31,12 @@ class Postprocessor:
         self.priors = torch.as_tensor(priors, dtype=torch.float32).contiguous().to(dev)
         assert self.priors.shape == (self.P, 4)
         B, P, NC, K = self.B, self.P, self.NC, self.K
-        self.conf = torch.empty((B, P, NC), dtype=torch.float32, device=dev)
+        # the product path (run -> od_detect) never materialises the confidence tensor; `conf` is filled on demand from the
+        # last pred (same kernel code, same bits) for callers that want the dense [B,P,NC] view (tests, head())
+        self._conf = None
+        self._pred = None
+        self._conf_valid = False
+        self.fused = P % 2 == 0 and NC <= 90
         self.boxes = torch.empty((B, P, 4), dtype=torch.float32, device=dev)
         self.keys = torch.empty((B, K), dtype=torch.int64, device=dev)  # u64 payload
         self.counts = torch.empty((B,), dtype=torch.int32, device=dev)
@@ -42,15 +47,41 @@ class Postprocessor:
         # kept detections of the batch as one record block + its pinned host mirror: ONE device->host copy per batch
         self.det = torch.empty((B, 1 + 6 * self.max_det), dtype=torch.float32, device=dev)
         self.det_host = torch.empty((B, 1 + 6 * self.max_det), dtype=torch.float32).pin_memory()
-        self.ws_topk = torch.empty((self.ws_topk_bytes,), dtype=torch.uint8, device=dev)
+        self._ws_topk = None  # only the three-call path (head / topk / nms separately) needs it
         self.ws_nms = torch.empty((self.ws_nms_bytes,), dtype=torch.uint8, device=dev)
+        self.ws_det_bytes = self.lib.od_detect_workspace_bytes(B, P, NC, K)
+        self.ws_det = torch.empty((self.ws_det_bytes,), dtype=torch.uint8, device=dev)
+        _lib.check(self.lib.od_detect_workspace_init(self.ctx.handle, self.ws_det.data_ptr(), self.ws_det_bytes, B, P, NC,
+                                                     _stream_ptr()), "od_detect_workspace_init")
+        torch.cuda.current_stream(dev).synchronize()  # the pipelines use this workspace on their own streams
+
+    @property
+    def ws_topk(self):
+        if self._ws_topk is None:
+            self._ws_topk = torch.empty((self.ws_topk_bytes,), dtype=torch.uint8, device=self.priors.device)
+        return self._ws_topk
+
+    @property
+    def conf(self):
+        """Dense confidences f32 [B,P,NC] of the last batch: written by head(), or computed on demand from the pred that
+        run() saw (od_head_postprocess: the same confidence code as the fused path, bit-identical values)."""
+        if self._conf is None:
+            self._conf = torch.empty((self.B, self.P, self.NC), dtype=torch.float32, device=self.priors.device)
+        if not self._conf_valid:
+            if self._pred is None:
+                raise _lib.OdError("Postprocessor.conf: nothing has been processed yet")
+            self.head(self._pred)
+        return self._conf
 
     def head(self, pred: torch.Tensor, clip=True):
         assert pred.dtype == torch.float32 and pred.is_contiguous() and tuple(pred.shape) == (self.B, self.P, self.NC + 6)
+        if self._conf is None:
+            self._conf = torch.empty((self.B, self.P, self.NC), dtype=torch.float32, device=self.priors.device)
         _lib.check(self.lib.od_head_postprocess(self.ctx.handle, pred.data_ptr(), self.priors.data_ptr(),
-                                                self.conf.data_ptr(), self.boxes.data_ptr(), self.B, self.P, self.NC,
+                                                self._conf.data_ptr(), self.boxes.data_ptr(), self.B, self.P, self.NC,
                                                 self.loc_scale, int(clip), _stream_ptr()), "od_head_postprocess")
-        return self.conf, self.boxes
+        self._pred, self._conf_valid = pred, True
+        return self._conf, self.boxes
 
     def topk(self, conf: torch.Tensor, conf_threshold: float):
         assert conf.dtype == torch.float32 and conf.is_contiguous()
@@ -69,10 +100,10 @@ class Postprocessor:
     def gather(self):
         """Queue the gather of this batch's kept detections (od_gather_detections) and its copy into the pinned host block
         on the current stream; read with detections_host() after the stream / event has been waited for."""
-        _lib.check(self.lib.od_gather_detections(self.ctx.handle, self.conf.data_ptr(), self.boxes.data_ptr(),
-                                                 self.keep_flat.data_ptr(), self.keep_count.data_ptr(), self.B, self.P,
-                                                 self.NC, self.max_det, self.det.data_ptr(), _stream_ptr()),
-                   "od_gather_detections")
+        _lib.check(self.lib.od_gather_detections_pred(self.ctx.handle, self._pred.data_ptr(), self.boxes.data_ptr(),
+                                                      self.keep_flat.data_ptr(), self.keep_count.data_ptr(), self.B, self.P,
+                                                      self.NC, self.max_det, self.det.data_ptr(), _stream_ptr()),
+                   "od_gather_detections_pred")
         self.det_host.copy_(self.det, non_blocking=True)
 
     def detections_host(self, n_valid):
@@ -87,7 +118,21 @@ class Postprocessor:
         return out
 
     def run(self, pred: torch.Tensor, conf_threshold: float):
-        """pred [B,P,C] -> (keep_flat i32 [B,max_det] (-1 padded), keep_count i32 [B]); conf/boxes stay on device."""
+        """pred [B,P,C] -> (keep_flat i32 [B,max_det] (-1 padded), keep_count i32 [B]); boxes / keys stay on device.
+        ONE C-ABI call (od_detect, five launches); run_unfused() is the same result through head -> topk -> nms."""
+        if not self.fused:
+            return self.run_unfused(pred, conf_threshold)
+        assert pred.dtype == torch.float32 and pred.is_contiguous() and tuple(pred.shape) == (self.B, self.P, self.NC + 6)
+        _lib.check(self.lib.od_detect(self.ctx.handle, pred.data_ptr(), self.priors.data_ptr(), self.B, self.P, self.NC,
+                                      self.loc_scale, 1, float(conf_threshold), self.K, self.iou_threshold, self.strict,
+                                      self.max_det, self.boxes.data_ptr(), None, self.keys.data_ptr(), self.counts.data_ptr(),
+                                      self.keep_flat.data_ptr(), self.keep_count.data_ptr(), self.ws_det.data_ptr(),
+                                      self.ws_det_bytes, self.ws_nms.data_ptr(), self.ws_nms_bytes, _stream_ptr()), "od_detect")
+        self._pred, self._conf_valid = pred, False
+        return self.keep_flat, self.keep_count
+
+    def run_unfused(self, pred: torch.Tensor, conf_threshold: float):
+        """The three-call path (od_head_postprocess -> od_topk_scores -> od_nms): materialises conf, same kept indices."""
         conf, boxes = self.head(pred)
         keys, counts = self.topk(conf, conf_threshold)
         return self.nms(boxes, keys, counts)

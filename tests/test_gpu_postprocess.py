@@ -130,3 +130,72 @@ def test_nms_small_counts(cuda):
     for b in range(B):
         ref, *_ = onms.detect_image(conf[b], boxes[b])
         assert kcount[b] == len(ref) and (keep[b, :len(ref)] == ref).all() and (keep[b, len(ref):] == -1).all()
+
+
+@pytest.mark.parametrize("mode", ["random", "trained_like", "ties", "few", "none", "all_equal", "one_hot_row"])
+@pytest.mark.parametrize("size,K", [((320, 320), 1024), ((96, 160), 300)], ids=["320-K1024", "96x160-K300"])
+def test_fused_detect_equals_the_three_call_path(cuda, mode, size, K):
+    """od_detect (one call, five launches, no confidence tensor) against od_head_postprocess -> od_topk_scores -> od_nms on
+    the same pred: boxes, counts, the key SET, kept indices and kept counts bit for bit -- for dense random logits, a
+    trained-like map (a few confident priors over a quiet background), heavy ties, fewer than K candidates, none at all, all
+    scores equal (every score in the threshold bin: the workgroup-local candidate buffer overflows to the global list) and a
+    single hot prior per image; called three times in a row (the workspace cleans itself), with two thresholds."""
+    B = 3
+    pp, priors = _pp(cuda, B, size=size, topk=K)
+    P = len(priors)
+    rng = np.random.default_rng(5)
+    pred = rng.normal(0, 2, (B, P, 26)).astype(np.float32)
+    thr = 0.01
+    if mode == "trained_like":
+        pred[..., 0], pred[..., 1] = 4.0 + rng.normal(0, 0.3, (B, P)), -4.0 + rng.normal(0, 0.3, (B, P))
+        hot = rng.integers(0, P, (B, 40))
+        for b in range(B):
+            pred[b, hot[b], 0], pred[b, hot[b], 1] = -3.0, 3.0
+            pred[b, hot[b], 2 + rng.integers(0, 20, 40)] += 6.0
+    elif mode == "ties":
+        pred[..., :22] = np.round(pred[..., :22])  # few distinct logits -> many exactly equal confidences
+    elif mode == "few":
+        pred[..., 0], pred[..., 1] = 9.0, -9.0  # objectness ~ 1e-8
+        pred[:, :17, 0], pred[:, :17, 1] = -2.0, 2.0  # 17 live priors: 340 scores, most above the threshold
+    elif mode == "none":
+        pred[..., 0], pred[..., 1] = 20.0, -20.0
+    elif mode == "all_equal":
+        pred[...] = 0.0  # every conf = 0.5 / 20: one bin holds all P * 20 scores, the index decides
+        thr = 0.02
+    elif mode == "one_hot_row":
+        pred[..., 0], pred[..., 1] = 20.0, -20.0
+        pred[:, 7, 0], pred[:, 7, 1] = -5.0, 5.0
+    pt = torch.from_numpy(pred).to(cuda)
+    first_counts = None
+    for thr_i in (thr, 0.3):
+        kf0, kc0 = pp.run_unfused(pt, thr_i)
+        torch.cuda.synchronize()
+        ref = dict(boxes=pp.boxes.clone(), keys=_sorted_valid(pp.keys, pp.counts), kf=kf0.clone(), kc=kc0.clone(),
+                   conf=pp.conf.clone())
+        if first_counts is None:
+            first_counts = (ref["keys"][1].copy(), int(kc0.sum()))
+        for _rep in range(3):
+            pp.boxes.zero_(), pp.keys.zero_(), pp.counts.zero_(), pp.keep_flat.zero_(), pp.keep_count.zero_()
+            kf, kc = pp.run(pt, thr_i)
+            torch.cuda.synchronize()
+            assert torch.equal(pp.boxes, ref["boxes"])
+            got_keys, got_counts = _sorted_valid(pp.keys, pp.counts)
+            assert (got_counts == ref["keys"][1]).all(), (mode, got_counts, ref["keys"][1])
+            for b in range(B):
+                assert np.array_equal(got_keys[b], ref["keys"][0][b]), (mode, b)
+                raw = pp.keys[b].cpu().numpy().view(np.uint64)
+                assert (np.diff(raw[:got_counts[b]].astype(np.float64)) <= 0).all() and (raw[got_counts[b]:] == 0).all()
+            assert torch.equal(kc, ref["kc"]) and torch.equal(kf, ref["kf"]), mode
+            assert torch.equal(pp.conf, ref["conf"])  # the on-demand dense view = the same bits
+            # the record block: confidences recomputed from pred equal the dense tensor's
+            pp.gather()
+            torch.cuda.synchronize()
+            for b, (flat, cf, bx) in enumerate(pp.detections_host(B)):
+                n = int(kc[b])
+                assert np.array_equal(flat, kf[b, :n].cpu().numpy())
+                assert np.array_equal(cf, ref["conf"][b].reshape(-1)[flat.astype(np.int64)].cpu().numpy())
+                assert np.array_equal(bx, ref["boxes"][b][(flat // 20).astype(np.int64)].cpu().numpy())
+    if mode == "none":
+        assert first_counts[1] == 0
+    if mode == "all_equal":
+        assert (first_counts[0] == K).all()
