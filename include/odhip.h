@@ -64,6 +64,11 @@ long od_sizeof(const char* struct_name);
 long od_offsetof(const char* struct_name, const char* field_name);
 int od_struct_fields(const char* struct_name, char* buf, int buf_bytes);
 
+/* A stream whose kernels run on a subset of the compute units only (bit i of cu_bits[i / 32] = CU i enabled).  The training
+ * step (Trainer, OD_TRAIN_WSTREAM_CUS) can confine its weight-gradient chain to one; destroy with od_stream_destroy. */
+int od_stream_create_cu_mask(od_ctx* ctx, const uint32_t* cu_bits, int n_words, void** out_stream);
+int od_stream_destroy(od_ctx* ctx, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K1/K2: fused conv2d forward.  Replaces the Keras Conv2D+BatchNormalization+activation(+Add) layers
  * that `ObjectDetector.predict` executes (reference voc_validate.py:27; network per docs/MODEL.md:5-21).
@@ -118,6 +123,18 @@ typedef struct od_conv_desc {
   int32_t act2;
   float alpha2;
   int32_t pad2_;
+  /* optional (nseg <= 1: none): GROUPED launch -- the same layer (w, scale, bias, activation, B, Cin, Cout, 3x3, stride 1,
+   * out_dtype / out_batch_stride / out_pix_stride) applied to nseg <= 3 input maps of different sizes, the prediction
+   * module whose weights the pyramid levels share (reference docs/MODEL.md:8): segment i reads seg_x[i] f16
+   * [B, seg_H[i], seg_W[i], Cin] and writes seg_out[i]; x / out / H / W are ignored.  No residual, w2, bn_partials or
+   * transposed mode.  One launch when the 8-wave kernel takes the layer (every m-tile lies inside one segment), otherwise
+   * the library issues the nseg launches itself -- identical results either way. */
+  int32_t nseg;
+  int32_t pad3_;
+  const void* seg_x[3];
+  void* seg_out[3];
+  int32_t seg_H[3];
+  int32_t seg_W[3];
 } od_conv_desc;
 
 int od_conv_weight_dims(int cout, int cin, int ksize, int* cout_pad, int* kpad);

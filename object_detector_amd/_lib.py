@@ -35,6 +35,9 @@ class ConvDesc(C.Structure):
         # the pointwise layer that consumes this launch's output (None = no second layer)
         ("w2", C.c_void_p), ("scale2", C.c_void_p), ("bias2", C.c_void_p), ("out2", C.c_void_p),
         ("Cout2", C.c_int32), ("act2", C.c_int32), ("alpha2", C.c_float), ("pad2_", C.c_int32),
+        # grouped launch: the same layer over nseg <= 3 maps of different sizes (0 / 1 = an ordinary launch)
+        ("nseg", C.c_int32), ("pad3_", C.c_int32), ("seg_x", C.c_void_p * 3), ("seg_out", C.c_void_p * 3),
+        ("seg_H", C.c_int32 * 3), ("seg_W", C.c_int32 * 3),
     ]
 
 
@@ -113,6 +116,8 @@ _PROTOS = {
     "od_sizeof": (C.c_long, [C.c_char_p]),
     "od_offsetof": (C.c_long, [C.c_char_p, C.c_char_p]),
     "od_struct_fields": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
+    "od_stream_create_cu_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "od_stream_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "od_conv_weight_dims": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "od_conv_num_tile_cfgs": (C.c_int, []),
     "od_conv2d_fwd": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_void_p]),

@@ -72,7 +72,8 @@ const std::vector<StructInfo>& od_struct_table() {
         OD_F(od_conv_desc, splitk_workspace), OD_F(od_conv_desc, splitk_workspace_bytes), OD_F(od_conv_desc, bn_partials),
         OD_F(od_conv_desc, bn_partials_bytes), OD_F(od_conv_desc, w2), OD_F(od_conv_desc, scale2), OD_F(od_conv_desc, bias2),
         OD_F(od_conv_desc, out2), OD_F(od_conv_desc, Cout2), OD_F(od_conv_desc, act2), OD_F(od_conv_desc, alpha2),
-        OD_F(od_conv_desc, pad2_)}},
+        OD_F(od_conv_desc, pad2_), OD_F(od_conv_desc, nseg), OD_F(od_conv_desc, pad3_), OD_F(od_conv_desc, seg_x),
+        OD_F(od_conv_desc, seg_out), OD_F(od_conv_desc, seg_H), OD_F(od_conv_desc, seg_W)}},
       {"od_bneck_desc", sizeof(od_bneck_desc),
        {OD_F(od_bneck_desc, x), OD_F(od_bneck_desc, w1), OD_F(od_bneck_desc, scale1), OD_F(od_bneck_desc, bias1),
         OD_F(od_bneck_desc, w3), OD_F(od_bneck_desc, scale3), OD_F(od_bneck_desc, bias3), OD_F(od_bneck_desc, out),
@@ -155,6 +156,24 @@ extern "C" int od_ctx_destroy(od_ctx* ctx) {
   if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   if (ctx->ones) (void)hipFree(ctx->ones);
   delete ctx;
+  return OD_OK;
+}
+
+// A HIP stream confined to a subset of the CUs (hipExtStreamCreateWithCUMask): the training step runs its weight-gradient
+// chain on one beside the dz -> dx chain, so that the two chains stop evicting each other's tiles from every CU.
+// cu_bits: bit i of word i / 32 = CU i enabled.
+extern "C" int od_stream_create_cu_mask(od_ctx* ctx, const uint32_t* cu_bits, int n_words, void** out) {
+  OD_REQUIRE(ctx && cu_bits && n_words > 0 && out, "od_stream_create_cu_mask: bad argument");
+  OD_CHECK_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = nullptr;
+  OD_CHECK_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_bits));
+  *out = (void*)s;
+  return OD_OK;
+}
+
+extern "C" int od_stream_destroy(od_ctx* ctx, void* stream) {
+  OD_REQUIRE(ctx && stream, "od_stream_destroy: bad argument");
+  OD_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
   return OD_OK;
 }
 

@@ -163,8 +163,10 @@ static __device__ __forceinline__ void e8_epilogue_direct(const ConvKP& p, f32x4
 // BUF = 0: global_load_lds_dwordx4 with 64-bit per-lane addresses and the zero page (kept for A/B timing).
 // PW: the pointwise (1x1) layer that consumes this tile's 256 output channels runs in the epilogue (see the end of the
 // kernel); the launch then writes both tensors and the 1x1 layer has no launch of its own.
-template <int KS, int MF1, int DBG = 0, int BUF = 1, bool PW = false>
-__global__ __launch_bounds__(512, 2) void od_conv_8ph(ConvKP p) {
+// SEG: grouped launch -- the m-tile index selects one of up to three input maps (x, out, H, W, M come from the segment
+// table; stride 1, no residual): the prediction module shared by the pyramid levels as ONE launch per layer.
+template <int KS, int MF1, int DBG = 0, int BUF = 1, bool PW = false, bool SEG = false>
+__global__ __launch_bounds__(512, 2) void od_conv_8ph(ConvKP p_in) {
   constexpr int MF0 = 4, MT = MF0 + MF1, WROWS = MT * 16, BM = 2 * WROWS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -182,12 +184,30 @@ __global__ __launch_bounds__(512, 2) void od_conv_8ph(ConvKP p) {
 
   int logical;
   {
-    const int nt = p.mtiles * p.ntiles;
-    const int pid = p.splitk > 1 ? (int)blockIdx.x / p.splitk : (int)blockIdx.x;
+    const int nt = p_in.mtiles * p_in.ntiles;
+    const int pid = p_in.splitk > 1 ? (int)blockIdx.x / p_in.splitk : (int)blockIdx.x;
     const int q = nt >> 3, r = nt & 7, xcd = pid & 7, loc = pid >> 3;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int tm = logical / p.ntiles, tn = logical - tm * p.ntiles;
+  int tm = logical / p_in.ntiles;
+  const int tn = logical - tm * p_in.ntiles;
+  ConvKP p_seg;  // SEG only: the parameter block with the map-dependent fields of this tile's segment
+  if (SEG) {     // wave-uniform: everything below sees one ordinary dense map
+    p_seg = p_in;
+    int sg = 0;
+    if (tm >= p_in.seg_tile0[1]) sg = 1;
+    if (p_in.nseg > 2 && tm >= p_in.seg_tile0[2]) sg = 2;
+    tm -= p_in.seg_tile0[sg];
+    p_seg.x = p_in.seg_x[sg];
+    p_seg.out = p_in.seg_out[sg];
+    p_seg.H = p_seg.Ho = p_in.seg_H[sg];
+    p_seg.W = p_seg.Wo = p_in.seg_W[sg];
+    p_seg.HoWo = p_seg.H * p_seg.W;
+    p_seg.M = p_in.seg_M[sg];
+    p_seg.x_bytes = (unsigned)p_seg.M * (unsigned)p_in.Cin * 2u;
+    if (p_in.obs == 0) p_seg.obs = (long long)p_seg.HoWo * p_in.Cout;  // dense output: the batch stride is this map's
+  }
+  const ConvKP& p = SEG ? p_seg : p_in;
   const int m0 = tm * BM, n0 = tn * E_BN;
   const int nk_all = p.Ktot / E_BK;
   const int ks0 = p.splitk > 1 ? ((int)blockIdx.x % p.splitk) * p.steps_per_split : 0;
@@ -615,13 +635,16 @@ struct E8Entry {
   const void* k3pw;
   const char* name1pw;
   const char* name3pw;
+  const void* k3seg;  // grouped launch over several maps (3x3)
+  const char* name3seg;
 };
 #define OD_E8(MF1)                                                                                        \
   {                                                                                                       \
     32 * (4 + MF1), (const void*)&od_conv_8ph<1, MF1>, (const void*)&od_conv_8ph<3, MF1>,                 \
         "od_conv_8ph<1, " #MF1 ", 0, 1, false>", "od_conv_8ph<3, " #MF1 ", 0, 1, false>",                             \
         (const void*)&od_conv_8ph<1, MF1, 0, 1, true>, (const void*)&od_conv_8ph<3, MF1, 0, 1, true>,     \
-        "od_conv_8ph<1, " #MF1 ", 0, 1, true>", "od_conv_8ph<3, " #MF1 ", 0, 1, true>"                    \
+        "od_conv_8ph<1, " #MF1 ", 0, 1, true>", "od_conv_8ph<3, " #MF1 ", 0, 1, true>",                   \
+        (const void*)&od_conv_8ph<3, MF1, 0, 1, false, true>, "od_conv_8ph<3, " #MF1 ", 0, 1, false, true>" \
   }
 const E8Entry g_e8[] = {OD_E8(4), OD_E8(3), OD_E8(2), OD_E8(1)};  // BM = 256, 224, 192, 160
 const void* const g_e8_dbg[][2] = {{(const void*)&od_conv_8ph<3, 4, 1>, "od_conv_8ph<3, 4, dbg1>"},
@@ -645,6 +668,11 @@ bool od_conv_8ph_select(int idx, const ConvKP& p, int ksize, ConvKernelInfo* inf
   const bool pw = p.w2 != nullptr;  // the caller (od_conv2d_fwd) has checked od_conv_8ph_can_fuse_pointwise
   info->fn = ksize == 1 ? (pw ? e.k1pw : e.k1) : (pw ? e.k3pw : e.k3);
   info->name = ksize == 1 ? (pw ? e.name1pw : e.name1) : (pw ? e.name3pw : e.name3);
+  if (p.nseg > 1) {
+    if (ksize != 3 || pw || p.stride != 1 || p.res_mode != OD_RES_NONE) return false;
+    info->fn = e.k3seg;
+    info->name = e.name3seg;
+  }
   if (idx == 0 && ksize == 3 && p.dbg && !pw) {
     const int di = p.dbg == 1 ? 0 : p.dbg == 2 ? 1 : p.dbg == 8 ? 2 : p.dbg == 16 ? 3 : p.dbg == 32 ? 4 : p.dbg == 64 ? 5 : p.dbg == 128 ? 6 : -1;
     if (di >= 0) {

@@ -37,6 +37,13 @@ struct ConvKP {
   float alpha2;
   unsigned w2_bytes;
   int K2stride;
+  // grouped launch (od_conv_desc.nseg > 1; 8-wave kernel only): the same layer over nseg input maps of different sizes,
+  // m-tiles of segment s = [seg_tile0[s], seg_tile0[s + 1]); a tile never straddles two segments
+  int nseg;
+  int seg_tile0[4];
+  const f16* seg_x[3];
+  void* seg_out[3];
+  int seg_H[3], seg_W[3], seg_M[3];
 };
 
 static __device__ __forceinline__ void glds16(const void* gptr, void* lptr) {

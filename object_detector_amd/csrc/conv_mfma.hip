@@ -536,6 +536,33 @@ static int od_conv2d_fwd_main(od_ctx* ctx, const od_conv_desc* d, hipStream_t st
 static int od_conv2d_fwd_impl2(od_ctx* ctx, const od_conv_desc* d, hipStream_t stream, const char** kernel_name, bool dry_run,
                                int* mtiles_out) {
   bool fused = false;
+  if (d && d->nseg > 1) {
+    // grouped launch: one launch when the 8-wave kernel takes the layer, else one ordinary launch per segment
+    OD_REQUIRE(d->nseg <= 3, "od_conv2d_fwd: nseg %d > 3", d->nseg);
+    OD_REQUIRE(d->ksize == 3 && d->stride == 1 && d->res_mode == OD_RES_NONE && !d->w2 && !d->bn_partials && !d->transposed,
+               "od_conv2d_fwd: a grouped launch (nseg > 1) is a 3x3 stride-1 layer without residual / w2 / bn_partials / "
+               "transposed mode");
+    for (int i = 0; i < d->nseg; ++i)
+      OD_REQUIRE(d->seg_x[i] && d->seg_out[i] && d->seg_H[i] > 0 && d->seg_W[i] > 0, "od_conv2d_fwd: segment %d is incomplete", i);
+    od_conv_desc q = *d;  // the first segment stands in for x / out / H / W in the shared validation
+    q.x = d->seg_x[0];
+    q.out = d->seg_out[0];
+    q.H = d->seg_H[0];
+    q.W = d->seg_W[0];
+    bool grouped = false;
+    int rc = od_conv2d_fwd_main(ctx, &q, stream, kernel_name, dry_run, mtiles_out, &grouped);
+    if (rc != OD_OK || grouped) return rc;
+    for (int i = 0; i < d->nseg; ++i) {
+      q.nseg = 0;
+      q.x = d->seg_x[i];
+      q.out = d->seg_out[i];
+      q.H = d->seg_H[i];
+      q.W = d->seg_W[i];
+      rc = od_conv2d_fwd_main(ctx, &q, stream, i == 0 ? kernel_name : nullptr, dry_run, nullptr, nullptr);
+      if (rc != OD_OK) return rc;
+    }
+    return OD_OK;
+  }
   const int rc = od_conv2d_fwd_main(ctx, d, stream, kernel_name, dry_run, mtiles_out, &fused);
   if (rc != OD_OK || !d->w2 || fused || dry_run) return rc;
   const int pad = d->ksize / 2;
@@ -599,7 +626,11 @@ static int od_conv2d_fwd_main(od_ctx* ctx, const od_conv_desc* d, hipStream_t st
   const long long M64 = (long long)d->B * Ho * Wo;
   OD_REQUIRE(M64 * d->Cout < (1LL << 31) && (long long)d->B * d->H * d->W * d->Cin < (1LL << 31),
              "od_conv2d_fwd: tensor too large for 32-bit element offsets");
-  const int M = (int)M64;
+  const bool grouped = d->nseg > 1;  // (validated by the caller: 3x3, stride 1, plain epilogue; q.H / q.W = segment 0)
+  long long Mg = 0;
+  for (int i = 0; grouped && i < d->nseg; ++i) Mg += (long long)d->B * d->seg_H[i] * d->seg_W[i];
+  OD_REQUIRE(!grouped || Mg * d->Cout < (1LL << 31), "od_conv2d_fwd: grouped launch too large for 32-bit element offsets");
+  const int M = grouped ? (int)Mg : (int)M64;
 
   const bool want_stats = d->bn_partials != nullptr;
   if (want_stats)
@@ -654,6 +685,10 @@ static int od_conv2d_fwd_main(od_ctx* ctx, const od_conv_desc* d, hipStream_t st
   const int cfg_e8 = kNumCfgs;
   OD_REQUIRE(cfg < cfg_e8 + od_conv_8ph_num_cfgs(), "od_conv2d_fwd: tile_cfg %d out of range", cfg);
   const bool use_e8 = cfg >= cfg_e8;
+  if (grouped && !(use_e8 && d->Cin % 64 == 0)) {  // the table kernels have no segment table: one launch per segment
+    if (fused_out) *fused_out = false;
+    return OD_OK;
+  }
   OD_REQUIRE(!(want_stats && use_e8), "od_conv2d_fwd: bn_partials is supported by the table kernels only (tile_cfg %d)", cfg);
   OD_REQUIRE(!tconv || !use_e8, "od_conv2d_fwd: transposed mode runs on the table kernels only (tile_cfg %d)", cfg);
   TileCfg tc = g_cfgs[use_e8 ? 0 : cfg];
@@ -686,6 +721,7 @@ static int od_conv2d_fwd_main(od_ctx* ctx, const od_conv_desc* d, hipStream_t st
   p.res_mode = d->res_mode;
   p.out_f32 = d->out_dtype == OD_DT_F32;
   p.stats = d->bn_partials;
+  p.nseg = grouped ? d->nseg : 0;
   p.w2 = nullptr;  // set below when the selected kernel runs the consuming pointwise layer in its epilogue
   p.scale2 = d->scale2;
   p.bias2 = d->bias2;
@@ -722,6 +758,27 @@ static int od_conv2d_fwd_main(od_ctx* ctx, const od_conv_desc* d, hipStream_t st
     tc.lds = lds;
   }
   p.mtiles = od_ceil_div(M, tc.BM);
+  if (grouped) {  // every segment's rows padded to whole m-tiles
+    int t0 = 0;
+    for (int i = 0; i < 3; ++i) {
+      p.seg_tile0[i] = t0;
+      p.seg_x[i] = nullptr;
+      p.seg_out[i] = nullptr;
+      p.seg_H[i] = p.seg_W[i] = p.seg_M[i] = 0;
+      if (i < d->nseg) {
+        p.seg_x[i] = (const f16*)d->seg_x[i];
+        p.seg_out[i] = d->seg_out[i];
+        p.seg_H[i] = d->seg_H[i];
+        p.seg_W[i] = d->seg_W[i];
+        p.seg_M[i] = d->B * d->seg_H[i] * d->seg_W[i];
+        t0 += od_ceil_div(p.seg_M[i], tc.BM);
+      }
+    }
+    p.seg_tile0[3] = t0;
+    p.mtiles = t0;
+    if (!d->out_batch_stride) p.obs = 0;  // dense outputs: the kernel takes every segment's own H * W * Cout
+    if (fused_out) *fused_out = true;  // (the caller's "ran as one grouped launch" flag)
+  }
   p.Mq = 0;
   if (tconv) {  // rows per parity class padded to whole tiles, classes interleaved tile by tile (od_tconv_pixel)
     p.Mq = M / 4;
@@ -743,7 +800,7 @@ static int od_conv2d_fwd_main(od_ctx* ctx, const od_conv_desc* d, hipStream_t st
       return OD_ERR_WORKSPACE;
     }
   }
-  if (d->splitk_workspace && d->splitk != 1 && !tconv && !want_stats) {  // transposed mode orders its rows by parity class: no slabs
+  if (d->splitk_workspace && d->splitk != 1 && !tconv && !want_stats && !grouped) {  // transposed mode orders its rows by parity class: no slabs
     const int cus = ctx->num_cu > 0 ? ctx->num_cu : 256;
     const int tiles = p.mtiles * p.ntiles;
     const int nk = od_ceil_div(p.Ktot, tc.BK);
@@ -777,7 +834,7 @@ static int od_conv2d_fwd_main(od_ctx* ctx, const od_conv_desc* d, hipStream_t st
       if (!od_conv_8ph_select(cfg - cfg_e8, p, d->ksize, &e8, &lds)) return OD_ERR_INVALID;
     }
   }
-  if (fused_out) *fused_out = p.w2 != nullptr;
+  if (fused_out) *fused_out = grouped || p.w2 != nullptr;
   // weights/scale/bias are padded to a multiple of 256 output channels, so any BN <= 256 tile stays in bounds.
 
   // kernel variant: 1x1 / 3x3-uniform-tap / 3x3-generic (odd channel counts fall back to a config that has one)

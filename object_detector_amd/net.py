@@ -309,6 +309,40 @@ class Net:
             return out, ho, wo, out2
         return out, ho, wo
 
+    def _conv_grouped(self, name, xs, dims, cin, cout, act, outs=None, out_f32=False, obs=0, ops=0):
+        """One 3x3 stride-1 layer over several maps in ONE plan op (od_conv_desc.nseg): the prediction module shared by the
+        pyramid levels.  xs: input tensors, dims: [(h, w)], outs: raw output pointers (else dense f16 buffers are made)."""
+        wt, sc, bi = self._dev[name]
+        if outs is None:
+            bufs = [self._buf(h, w, cout) for h, w in dims]
+            outs = [t.data_ptr() for t in bufs]
+        else:
+            bufs = [None] * len(dims)
+        d = _lib.ConvDesc()
+        d.w, d.scale, d.bias = wt.data_ptr(), sc.data_ptr(), bi.data_ptr()
+        d.B, d.Cin, d.Cout, d.ksize, d.stride = self.B, cin, cout, 3, 1
+        d.act, d.alpha = _lib.ACT_ENUM[act[0] if act else None], float(act[1]) if act else 0.0
+        d.out_dtype = _lib.OD_DT_F32 if out_f32 else _lib.OD_DT_F16
+        d.out_batch_stride, d.out_pix_stride = obs, ops
+        d.tile_cfg = self.tile_cfg.get(name, self.auto_cfg)
+        d.nseg = len(xs)
+        for i, (x, (h, w), o) in enumerate(zip(xs, dims, outs)):
+            d.seg_x[i], d.seg_out[i], d.seg_H[i], d.seg_W[i] = x.data_ptr(), o, h, w
+        op = _lib.PlanOp()
+        op.kind = _lib.OD_OP_CONV
+        op.conv = d
+        self.ops.append(op)
+        m = sum(self.B * h * w for h, w in dims)
+        if self.splitk and max(self.B * h * w for h, w in dims) * cout <= (1 << 22):
+            # small maps (batch 1): the library runs the segments as separate launches and may split K for them
+            self._splitk_elems = max(self._splitk_elems, max(self.B * h * w for h, w in dims) * cout)
+            self._splitk_descs.append(len(self.ops) - 1)
+        osz = 4 if out_f32 else 2
+        self.op_info.append(dict(name=name, flops=2.0 * m * cout * 9 * cin,
+                                 bytes=float(m * cin * 2 + m * cout * osz + cout * 9 * cin * 2), shape=(m, cout, 9 * cin),
+                                 kind="conv_group", xs=list(xs), dims=list(dims), outs=bufs, act=act, out_f32=out_f32))
+        return bufs
+
     def _bneck(self, name, x, h, w, ch, act):
         """one fused residual block (1x1 ch -> ch/2, 3x3 ch/2 -> ch, + x): od_bottleneck_fwd"""
         w1, s1, b1 = self._dev[name + ".a"]
@@ -435,7 +469,21 @@ class Net:
         # shared prediction module; the last conv writes f32 logits into pred[:, off:off+h*w*8, :]
         off = 0
         cout = W.NUM_PRIORS * self.C
-        for (x, h, w), xs in zip(self.levels, (p3s, p4s, p5s)):
+        group = (self.precision == "f16" and self.tower == 1 and nc % 64 == 0
+                 and os.environ.get("OD_GROUP_HEAD", "1") != "0")
+        if group:
+            # the prediction module's weights are shared by the three levels (docs/MODEL.md:8): ONE launch per layer over
+            # all 67 200 x B / 8 rows instead of three (the 20^2 and 10^2 launches filled 50 and 13 of 256 CUs)
+            dims = [(h, w) for _x, h, w in self.levels]
+            ts = self._conv_grouped("h.t0", [x for x, _h, _w in self.levels], dims, nc, nc, hact)
+            ptrs, rows = [], []
+            for h, w in dims:
+                ptrs.append(self.pred.data_ptr() + off * self.C * 4)
+                rows.append((off, h * w * W.NUM_PRIORS))
+                off += h * w * W.NUM_PRIORS
+            self._conv_grouped("h.out", ts, dims, nc, cout, None, outs=ptrs, out_f32=True, obs=self.P * self.C, ops=cout)
+            self.op_info[-1]["pred_rows"] = rows
+        for (x, h, w), xs in ([] if group else zip(self.levels, (p3s, p4s, p5s))):
             t, ts = x, xs
             for i in range(self.tower):
                 t, ts, _ = self._neck_conv(f"h.t{i}", t, ts, h, w, nc, nc, 3, hact,

@@ -67,6 +67,33 @@ def conv2d(x: torch.Tensor, w_ohwi: np.ndarray, scale: np.ndarray, bias: np.ndar
     return out
 
 
+def conv2d_grouped(xs, w_ohwi: np.ndarray, scale: np.ndarray, bias: np.ndarray, act=None, alpha=0.0, out_f32=False,
+                   tile_cfg=-1):
+    """The same 3x3 stride-1 layer over several maps xs = [f16 [B,H_i,W_i,Cin]] in one call (od_conv_desc.nseg: the
+    prediction module shared by the pyramid levels, reference docs/MODEL.md:8) -> [out_i [B,H_i,W_i,Cout]]."""
+    ctx = _ctx(xs[0])
+    B, Cin = xs[0].shape[0], xs[0].shape[3]
+    Cout, k = w_ohwi.shape[0], w_ohwi.shape[1]
+    wp = torch.from_numpy(pack_conv_weight(w_ohwi)).to(xs[0].device)
+    sc = torch.from_numpy(pad_vec(np.asarray(scale, np.float32), wp.shape[0])).to(xs[0].device)
+    bi = torch.from_numpy(pad_vec(np.asarray(bias, np.float32), wp.shape[0])).to(xs[0].device)
+    outs = [torch.empty(tuple(x.shape[:3]) + (Cout,), dtype=torch.float32 if out_f32 else torch.float16, device=x.device)
+            for x in xs]
+    d = _lib.ConvDesc()
+    d.w, d.scale, d.bias = wp.data_ptr(), sc.data_ptr(), bi.data_ptr()
+    d.B, d.Cin, d.Cout, d.ksize, d.stride = B, Cin, Cout, k, 1
+    d.act, d.alpha = _lib.ACT_ENUM[act], float(alpha)
+    d.out_dtype = _lib.OD_DT_F32 if out_f32 else _lib.OD_DT_F16
+    d.tile_cfg = tile_cfg
+    d.nseg = len(xs)
+    for i, (x, o) in enumerate(zip(xs, outs)):
+        assert x.dtype == torch.float16 and x.is_contiguous() and x.shape[0] == B and x.shape[3] == Cin
+        d.seg_x[i], d.seg_out[i], d.seg_H[i], d.seg_W[i] = x.data_ptr(), o.data_ptr(), x.shape[1], x.shape[2]
+    _lib.check(ctx.lib.od_conv2d_fwd(ctx.handle, C.byref(d), _stream_ptr()), "od_conv2d_fwd(grouped)")
+    torch.cuda.current_stream().synchronize()  # the packed weights above are temporaries
+    return outs
+
+
 def bottleneck(x: torch.Tensor, w1_ohwi: np.ndarray, scale1, bias1, w3_ohwi: np.ndarray, scale3, bias3, act="leaky",
                alpha=0.1):
     """Fused residual block x + act(bn3(conv3x3(act(bn1(conv1x1(x)))))): x f16 [B,H,W,C] -> f16 [B,H,W,C]."""

@@ -141,6 +141,22 @@ class Trainer:
         self.dzs = [torch.empty(mx, dtype=torch.float16, device=dev) for _ in range(3 if self.use_wstream else 1)]
         self.dz = self.dzs[0]
         self.wstream = torch.cuda.Stream(device=dev) if self.use_wstream else None
+        # OD_TRAIN_WSTREAM_CUS="first:count[:stride]": the weight-gradient stream confined to `count` CUs starting at `first`
+        # (every `stride`-th CU; an experiment knob -- profiles/r03/train_cu_mask.txt)
+        spec = os.environ.get("OD_TRAIN_WSTREAM_CUS", "")
+        if self.use_wstream and spec:
+            parts = [int(v) for v in spec.split(":")]
+            first, count, stride = parts[0], parts[1], (parts[2] if len(parts) > 2 else 1)
+            ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+            bits = [0] * ((ncu + 31) // 32)
+            for i in range(count):
+                cu = (first + i * stride) % ncu
+                bits[cu // 32] |= 1 << (cu % 32)
+            arr = (C.c_uint32 * len(bits))(*bits)
+            hnd = C.c_void_p()
+            _lib.check(self.lib.od_stream_create_cu_mask(self.ctx.handle, arr, len(bits), C.byref(hnd)), "od_stream_create_cu_mask")
+            self._masked_stream = hnd
+            self.wstream = torch.cuda.ExternalStream(hnd.value, device=dev)
         self._wg_done = [None] * len(self.dzs)
         # gradient exchange: buckets of whole layers from the END of the flat buffer (the order backward finishes them),
         # each all-reduced on its own stream as soon as its last layer is final -> the RCCL traffic overlaps the rest of

@@ -243,6 +243,42 @@ def test_conv_split_k(cuda, case):
     assert (err <= tol).all(), err.max()
 
 
+@pytest.mark.parametrize("case", [
+    # B, [(H, W)], Cin, Cout, act, out_f32, cfg
+    (8, [(40, 40), (20, 20), (10, 10)], 256, 256, "elu", False, -2),     # the prediction tower at 8 x 320^2 (8-wave kernel)
+    (8, [(40, 40), (20, 20), (10, 10)], 256, 208, None, True, -2),       # the prediction conv: f32, Cout = 208
+    (3, [(24, 40), (12, 20), (6, 10)], 128, 256, "leaky", False, NE8),   # ragged last tiles in every segment, BM = 256
+    (3, [(24, 40), (12, 20), (6, 10)], 128, 256, "leaky", False, NE8 + 3),   # BM = 160
+    (2, [(12, 12), (6, 6)], 64, 128, "elu", False, NE8 + 1),             # two segments, second smaller than a tile
+    (1, [(40, 40), (20, 20), (10, 10)], 256, 256, "elu", False, -1),     # batch 1: the library falls back to one launch per level
+    (2, [(12, 12), (6, 6), (3, 3)], 64, 128, "elu", False, 4),           # an explicit table config: always one launch per level
+], ids=str)
+def test_conv_grouped_over_pyramid_levels(cuda, case):
+    """od_conv_desc.nseg: the same 3x3 layer over several maps in ONE launch (8-wave kernel, every m-tile inside one segment)
+    -- or as one launch per segment when another kernel is selected.  Every segment vs the f64 oracle, and bit-identical to
+    the ordinary launch of that segment alone on the same kernel."""
+    from object_detector_amd import ops
+    B, dims, Cin, Cout, act, out_f32, cfg = case
+    rng = np.random.default_rng(hash(str(case)) & 0xFFFF)
+    xs = [rng.normal(0, 1, (B, h, w, Cin)).astype(np.float16) for h, w in dims]
+    w = (rng.normal(0, 1, (Cout, 3, 3, Cin)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float16)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    bias = rng.normal(0, 0.1, Cout).astype(np.float32)
+    alpha = 0.1 if act == "leaky" else 1.0
+    xts = [torch.from_numpy(x).to(cuda) for x in xs]
+    outs = ops.conv2d_grouped(xts, w.astype(np.float32), scale, bias, act=act, alpha=alpha, out_f32=out_f32, tile_cfg=cfg)
+    torch.cuda.synchronize()
+    for x, xt, o in zip(xs, xts, outs):
+        ref = _ref(x.astype(np.float32), w.astype(np.float32), scale, bias, 1, act, alpha)
+        got = o.cpu().numpy().astype(np.float64)
+        err = np.abs(got - ref)
+        tol = 1e-3 * max(1.0, np.abs(ref).max()) + (2.0 ** -10 * np.abs(ref) if not out_f32 else 0)
+        assert got.shape == ref.shape and (err <= tol).all(), f"max err {err.max()}"
+        if cfg >= NE8:  # the same kernel family alone on this map: same K order per output element -> the same bits
+            single = ops.conv2d(xt, w.astype(np.float32), scale, bias, act=act, alpha=alpha, out_f32=out_f32, tile_cfg=cfg)
+            assert torch.equal(single, o)
+
+
 def test_conv_f32_strided_output(cuda):
     """prediction conv: Cout=208 (not a tile multiple), f32 logits written into a slice of pred[B,P,26]."""
     from object_detector_amd import ops

@@ -84,6 +84,27 @@ def _check_layers_in_isolation(net, params, tag):
     worst_frac, rows = 0.0, []
     for inf, kname in zip(net.op_info, net.time_ops()[1]):
         kind, name = inf["kind"], inf["name"]
+        if kind == "conv_group":  # the shared prediction module over the three levels in one launch: segment by segment
+            for si, (xt, out) in enumerate(zip(inf["xs"], inf["outs"])):
+                xf = xt.cpu().numpy().astype(np.float32)
+                r = run.conv(xf, name, act=inf["act"])
+                A = mag.conv(np.abs(xf), name)
+                if inf["out_f32"]:
+                    off, rows_n = inf["pred_rows"][si]
+                    d = net.pred[:, off:off + rows_n].cpu().numpy().reshape(r.shape)
+                    err = float((np.abs(d - r) / (2.0 ** -20 * A)).max())
+                    assert err <= 1.0, (name, si, err)
+                    rows.append((f"{name}[{si}]", kname, "f32", err, 0.0))
+                else:
+                    d = out.cpu().numpy().astype(np.float32)
+                    r16 = r.astype(np.float16).astype(np.float32)
+                    tol = _f16_ulp(r16) + np.float32(2.0 ** -20) * A
+                    mx = float((np.abs(d - r16) / tol).max())
+                    frac = float(np.mean(d != r16))
+                    rows.append((f"{name}[{si}]", kname, "f16", mx, frac))
+                    assert mx <= 1.0 and frac <= 0.02, f"{tag} {name}[{si}] ({kname}): {mx:.2f} x tol, {frac:.3%} differ"
+                    worst_frac = max(worst_frac, frac)
+            continue
         x = inf["x"].cpu().numpy()
         if kind == "first":
             r = run.first(x)

@@ -117,7 +117,7 @@ def test_integration_md_declarations_match_library():
     ns = {}
     exec(blocks[0].replace('C.CDLL("libodhip.so")', f'C.CDLL({str(_lib.LIB_PATH)!r})'), ns)  # its own asserts run here
     assert [f[0] for f in ns["ConvDesc"]._fields_] == [f[0] for f in _lib.ConvDesc._fields_]
-    assert ctypes.sizeof(ns["ConvDesc"]) == ctypes.sizeof(_lib.ConvDesc) == 208
+    assert ctypes.sizeof(ns["ConvDesc"]) == ctypes.sizeof(_lib.ConvDesc) == 288
     lib = _lib.load()
     for sym, proto in (("od_conv2d_fwd", _lib._PROTOS["od_conv2d_fwd"]), ("od_nms", _lib._PROTOS["od_nms"]),
                        ("od_topk_scores", _lib._PROTOS["od_topk_scores"]),
