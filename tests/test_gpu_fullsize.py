@@ -71,7 +71,7 @@ def _abs_params(params, names):
     return q
 
 
-def _check_layers_in_isolation(net, params, tag):
+def _check_layers_in_isolation(net, params, tag, done=None):
     """Every op of the plan against the oracle ON THE DEVICE'S OWN INPUT of that op.  Given bit-identical inputs the only
     differences left are the f32 accumulation order and the last ulp of exp(), so the device's f16 output must equal the
     oracle's rounded value except where the pre-rounding value sits on a rounding boundary:
@@ -84,6 +84,12 @@ def _check_layers_in_isolation(net, params, tag):
     worst_frac, rows = 0.0, []
     for inf, kname in zip(net.op_info, net.time_ops()[1]):
         kind, name = inf["kind"], inf["name"]
+        # `done`: (layer, kernel) pairs another plan of the same test already checked on its own inputs -- the second plan
+        # only re-checks the layers it runs on a DIFFERENT kernel (the oracle conv of every op is what this test costs)
+        if done is not None:
+            if (name, kname) in done:
+                continue
+            done.add((name, kname))
         if kind == "conv_group":  # the shared prediction module over the three levels in one launch: segment by segment
             for si, (xt, out) in enumerate(zip(inf["xs"], inf["outs"])):
                 xf = xt.cpu().numpy().astype(np.float32)
@@ -199,7 +205,8 @@ def test_inference_at_baseline_config(cuda, B, S):
     o = outs[0]
     rec = _logit_stats(o["pred"], ref, ref32)
     _assert_logits(rec, f"{B}x{S} throughput plan")
-    layer_rows = _check_layers_in_isolation(od._pipes[0].net, od.params, f"{B}x{S} throughput plan")
+    checked = set()
+    layer_rows = _check_layers_in_isolation(od._pipes[0].net, od.params, f"{B}x{S} throughput plan", checked)
     for b in range(B):  # configs[2]: "NMS index bit-exact vs CPU", every image
         r, *_ = onms.detect_image(o["conf"][b], o["boxes"][b], K=1024, conf_threshold=0.01, iou_threshold=0.45, max_det=200)
         assert o["cnt"][b] == len(r) and (o["keep"][b, :len(r)] == r).all(), f"image {b}: kept indices differ"
@@ -223,7 +230,9 @@ def test_inference_at_baseline_config(cuda, B, S):
     print("kernels of the latency-mode plan:", kernels1)
     rec1 = _logit_stats(pred1, ref, ref32)
     _assert_logits(rec1, f"{B}x{S} latency plan")
-    _check_layers_in_isolation(od1.net, od1.params, f"{B}x{S} latency plan")
+    n_before = len(checked)
+    _check_layers_in_isolation(od1.net, od1.params, f"{B}x{S} latency plan", checked)
+    print(f"latency plan: {len(checked) - n_before} (layer, kernel) pairs not already covered by the throughput plan")
     conf1, boxes1 = od1.post.conf.cpu().numpy(), od1.post.boxes.cpu().numpy()
     keep1, cnt1 = keep1.cpu().numpy(), cnt1.cpu().numpy()
     for b in range(B):
