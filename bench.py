@@ -224,12 +224,13 @@ def train_bench(a, rank, world, dev):
         torch.distributed.destroy_process_group()
 
 
-def run_infer(params, size, batch, inflight, steps, warmup, reps, rank, world, dev, graph=False):
+def run_infer(params, size, batch, inflight, steps, warmup, reps, rank, world, dev, graph=False, precision=None):
     """One step = one predict pass over a uint8 batch resident in HBM (network + decode + top-K + NMS).  With inflight > 1
     the step is queued on the next pipeline's stream and overlaps the tail of the previous steps; every step of a
     repetition is complete before its closing synchronize."""
     from object_detector_amd.detector import ObjectDetector
-    od = ObjectDetector(params, batch, (size, size), device=dev, use_multi_gpu=world > 1, n_inflight=inflight)
+    od = ObjectDetector(params, batch, (size, size), device=dev, use_multi_gpu=world > 1, n_inflight=inflight,
+                        precision=precision)
     rng = np.random.default_rng(1000 + rank)  # each rank its own shard of synthetic images
     x = torch.from_numpy(rng.integers(0, 256, (batch, size, size, 3), dtype=np.uint8)).to(dev)
     if od.n_inflight > 1:
@@ -247,17 +248,21 @@ def extra_block(params, a, dev):
     out = {}
     net_flops_320 = 29.01e9 + 7.2e9
 
-    def infer(key, size, batch, inflight, steps):
-        od, times = run_infer(params, size, batch, inflight, steps, max(3, steps // 5), a.reps, 0, 1, dev)
+    def infer(key, size, batch, inflight, steps, precision=None):
+        od, times = run_infer(params, size, batch, inflight, steps, max(3, steps // 5), a.reps, 0, 1, dev, precision=precision)
         el = _median(times)
         fl = net_flops_320 * (size / 320.0) ** 2 * batch
-        out[key] = {"workload": f"inference {size}x{size} batch {batch}, {inflight} in flight", "images_per_sec": round(batch * steps / el, 1),
+        what = "" if precision is None else (f", precision={precision} (every logit within 1e-3 x scale of the fp32 oracle: f32 "
+                                             f"residual stream of stages 4-5, f32 FPN sums, split operands in 6 neck/head layers)")
+        out[key] = {"workload": f"inference {size}x{size} batch {batch}, {inflight} in flight{what}", "images_per_sec": round(batch * steps / el, 1),
                     "ms_per_step": round(el / steps * 1e3, 4), "frac": round(fl * steps / el / 1e12 / PEAK_F16_TFLOPS, 4)}
         del od
         torch.cuda.empty_cache()
 
     infer("infer_320_b32_inflight1", 320, 32, 1, 20)
+    infer("infer_320_b32_inflight3_mixed_precision", 320, 32, 3, 20, precision="mixed")
     infer("infer_640_b16_inflight3", 640, 16, 3, 12)
+    infer("infer_640_b16_inflight3_mixed_precision", 640, 16, 3, 12, precision="mixed")
     infer("infer_640_b16_inflight1", 640, 16, 1, 12)
     infer("infer_320_b1_inflight3", 320, 1, 3, 100)
     infer("infer_320_b1_inflight1", 320, 1, 1, 100)
@@ -431,7 +436,8 @@ def main():
     try:
         import pathlib
         prof = pathlib.Path(__file__).resolve().parent / "profiles"
-        pj = next((q for q in (prof / "r02" / "pmc_traffic.json", prof / "r01" / "pmc_traffic.json") if q.exists()), None)
+        pj = next((q for q in (prof / "r03" / "pmc_traffic.json", prof / "r02" / "pmc_traffic.json",
+                                   prof / "r01" / "pmc_traffic.json") if q.exists()), None)
         if size == 320 and batch == 32 and pj is not None:
             for kname, rec in json.loads(pj.read_text())["kernels"].items():
                 if dom in kname:
@@ -490,6 +496,12 @@ def main():
                          "network_ms_per_batch": round(net_ms, 4),
                          "network_tflops": round(sum(i["flops"] for i in info) / (net_ms * 1e-3) / 1e12, 2),
                          "traffic": traffic,
+                         # all instantiations of the 8-wave kernel together (one source; the symbols differ in tile height,
+                         # fused second layer, grouped launch): what the kernel as such sustains over its launches of a step
+                         "kernel_family": (lambda fam: {"kernel": dom.split("<")[0], "launches_per_step": sum(v["n"] for v in fam),
+                                                        "achieved": round(sum(v["flops"] for v in fam) / (sum(v["ms"] for v in fam) * 1e-3) / 1e12, 2),
+                                                        "frac": round(sum(v["flops"] for v in fam) / (sum(v["ms"] for v in fam) * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4)})(
+                             [v for k, v in groups.items() if k.split("<")[0] == dom.split("<")[0]]),
                          # the other instantiations of the same 8-wave kernel (since round 2 the stage-3 launches also run
                          # the consuming 1x1 layer in their epilogue and are a kernel symbol of their own)
                          "same_kernel_other_instantiations": [

@@ -192,8 +192,8 @@ __global__ __launch_bounds__(512, 2) void od_conv_8ph(ConvKP p_in) {
   int tm = logical / p_in.ntiles;
   const int tn = logical - tm * p_in.ntiles;
   ConvKP p_seg;  // SEG only: the parameter block with the map-dependent fields of this tile's segment
-  if (SEG) {     // wave-uniform: everything below sees one ordinary dense map
-    p_seg = p_in;
+  if (SEG) p_seg = p_in;
+  if (SEG && p_in.nseg > 1) {  // wave-uniform: everything below sees one ordinary dense map
     int sg = 0;
     if (tm >= p_in.seg_tile0[1]) sg = 1;
     if (p_in.nseg > 2 && tm >= p_in.seg_tile0[2]) sg = 2;
@@ -641,9 +641,9 @@ struct E8Entry {
 #define OD_E8(MF1)                                                                                        \
   {                                                                                                       \
     32 * (4 + MF1), (const void*)&od_conv_8ph<1, MF1>, (const void*)&od_conv_8ph<3, MF1>,                 \
-        "od_conv_8ph<1, " #MF1 ", 0, 1, false>", "od_conv_8ph<3, " #MF1 ", 0, 1, false>",                             \
+        "od_conv_8ph<1, " #MF1 ", 0, 1, false, false>", "od_conv_8ph<3, " #MF1 ", 0, 1, false, false>",                             \
         (const void*)&od_conv_8ph<1, MF1, 0, 1, true>, (const void*)&od_conv_8ph<3, MF1, 0, 1, true>,     \
-        "od_conv_8ph<1, " #MF1 ", 0, 1, true>", "od_conv_8ph<3, " #MF1 ", 0, 1, true>",                   \
+        "od_conv_8ph<1, " #MF1 ", 0, 1, true, false>", "od_conv_8ph<3, " #MF1 ", 0, 1, true, false>",                   \
         (const void*)&od_conv_8ph<3, MF1, 0, 1, false, true>, "od_conv_8ph<3, " #MF1 ", 0, 1, false, true>" \
   }
 const E8Entry g_e8[] = {OD_E8(4), OD_E8(3), OD_E8(2), OD_E8(1)};  // BM = 256, 224, 192, 160
@@ -672,6 +672,18 @@ bool od_conv_8ph_select(int idx, const ConvKP& p, int ksize, ConvKernelInfo* inf
     if (ksize != 3 || pw || p.stride != 1 || p.res_mode != OD_RES_NONE) return false;
     info->fn = e.k3seg;
     info->name = e.name3seg;
+  } else if (ksize == 3 && !pw) {
+    // ordinary 3x3 launches run the segment-capable instantiation too (its segment table is empty: nseg <= 1), so that the
+    // kernel is ONE symbol whether or not a layer is grouped; OD_E8_ONE_SYMBOL=0 keeps the plain instantiation (A/B timing)
+    static int one = -1;
+    if (one < 0) {
+      const char* ev = getenv("OD_E8_ONE_SYMBOL");
+      one = ev ? atoi(ev) : 1;
+    }
+    if (one) {
+      info->fn = e.k3seg;
+      info->name = e.name3seg;
+    }
   }
   if (idx == 0 && ksize == 3 && p.dbg && !pw) {
     const int di = p.dbg == 1 ? 0 : p.dbg == 2 ? 1 : p.dbg == 8 ? 2 : p.dbg == 16 ? 3 : p.dbg == 32 ? 4 : p.dbg == 64 ? 5 : p.dbg == 128 ? 6 : -1;

@@ -89,12 +89,14 @@ def _streams_overlap(a, b, spin_cycles):
     return free
 
 
-def stream_queue_sets(device, n, candidates=6, seed_streams=()):
-    """n streams of `device` that overlap pairwise, chosen greedily from `candidates` fresh streams by the probe above
-    (about 2 ms per pair, a few dozen ms once per process); cached.  Falls back to creation order when the probe cannot
-    tell streams apart (e.g. a runtime that serialises everything)."""
+def stream_queue_sets(device, n, candidates=6, seed_streams=(), beside=None):
+    """n streams of `device` that overlap pairwise -- and with the stream `beside`, if given (the trainer's side streams must
+    run next to its main stream) -- chosen greedily from `candidates` fresh streams by the probe above (about 2 ms per pair,
+    a few dozen ms once per process); cached.  Falls back to creation order when the probe cannot tell streams apart (e.g.
+    a runtime that serialises everything)."""
     device = torch.device(device)
-    key = (device.index if device.index is not None else torch.cuda.current_device(), n)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), n,
+           None if beside is None else beside.cuda_stream)
     if key in _QUEUE_SETS:
         return _QUEUE_SETS[key]
     with torch.cuda.device(device):
@@ -114,10 +116,11 @@ def stream_queue_sets(device, n, candidates=6, seed_streams=()):
         per_ms = 200000 / max(e0.elapsed_time(e1), 1e-3)
         spin = int(max(1000, 2.0 * per_ms))
         chosen = []
+        fixed = [] if beside is None else [beside]
         for c in cands:
             if len(chosen) == n:
                 break
-            if all(_streams_overlap(q, c, spin) and _streams_overlap(c, q, spin) for q in chosen):
+            if all(_streams_overlap(q, c, spin) and _streams_overlap(c, q, spin) for q in fixed + chosen):
                 chosen.append(c)
         for c in cands:  # not enough distinguishable queues: take the rest in creation order
             if len(chosen) == n:

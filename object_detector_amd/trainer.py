@@ -140,7 +140,15 @@ class Trainer:
         self.use_wstream = os.environ.get("OD_TRAIN_WSTREAM", "1") != "0"
         self.dzs = [torch.empty(mx, dtype=torch.float16, device=dev) for _ in range(3 if self.use_wstream else 1)]
         self.dz = self.dzs[0]
-        self.wstream = torch.cuda.Stream(device=dev) if self.use_wstream else None
+        # the side streams (weight gradients, collectives) must sit on other hardware queues than the main stream, or nothing
+        # overlaps: which queue a fresh stream lands on depends on how many streams the process created before, so they are
+        # picked with the measured queue-overlap probe of detector.stream_queue_sets (12.9 instead of 10.6 ms per step when
+        # the trainer was built after a few detectors in one process)
+        from .detector import stream_queue_sets
+        with torch.cuda.device(dev):
+            side = stream_queue_sets(dev, 2, beside=torch.cuda.current_stream(dev)) if self.use_wstream else [None, None]
+        self._side_streams = side
+        self.wstream = side[0] if self.use_wstream else None
         # OD_TRAIN_WSTREAM_CUS="first:count[:stride]": the weight-gradient stream confined to `count` CUs starting at `first`
         # (every `stride`-th CU; an experiment knob -- profiles/r03/train_cu_mask.txt)
         spec = os.environ.get("OD_TRAIN_WSTREAM_CUS", "")
@@ -164,7 +172,8 @@ class Trainer:
         self.bucket_mb = float(os.environ.get("OD_TRAIN_BUCKET_MB", "32"))
         # with an RCCL communicator (comm) the collectives go through od_allreduce; without one but world_size > 1 they go
         # through torch.distributed's default group (gloo rehearsals on one GPU, CPU-side tests) -- same buckets, same streams
-        self.cstream = torch.cuda.Stream(device=dev) if ((self.comm is not None or self.world > 1) and self.bucket_mb > 0) else None
+        need_c = (self.comm is not None or self.world > 1) and self.bucket_mb > 0
+        self.cstream = (self._side_streams[1] or torch.cuda.Stream(device=dev)) if need_c else None
         self.payload_buf = (torch.empty(self.n_flat, dtype=torch.bfloat16, device=dev) if self.grad_payload == "bf16"
                             else None)
         self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)

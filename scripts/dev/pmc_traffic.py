@@ -23,7 +23,7 @@ def read(d, counter):
 def main():
     fetch, nf = read(sys.argv[1], "FETCH_SIZE")
     write, nw = read(sys.argv[2], "WRITE_SIZE")
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --steps 10, MI355X, round 2",
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --steps 10, MI355X",
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
            "kernels": {}}
     for k in sorted(fetch):

@@ -199,7 +199,8 @@ def test_inference_at_baseline_config(cuda, B, S):
     print("kernels of the throughput-mode plan:", kernels)
     if S == 320:
         assert any(k.startswith("od_conv_8ph") for k in kernels) and any("od_stem" in k for k in kernels)
-        assert any(k.startswith("od_conv_8ph") and k.endswith("true>") for k in kernels), "stage 3: 1x1 in the producer's epilogue"
+        assert any(k.startswith("od_conv_8ph") and k.endswith("true, false>") for k in kernels), "stage 3: 1x1 in the producer's epilogue"
+        assert any(k.startswith("od_conv_8ph") and k.endswith("false, true>") for k in kernels), "the prediction module as one grouped launch per layer"
     for o in outs[1:]:  # the three pipelines share the weights and must agree bit for bit
         assert np.array_equal(o["pred"], outs[0]["pred"]) and np.array_equal(o["keep"], outs[0]["keep"])
     o = outs[0]

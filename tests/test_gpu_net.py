@@ -207,6 +207,6 @@ def test_shape_driven_kernel_selection_at_odd_sizes(cuda, case, monkeypatch):
         for b in range(B):
             r, *_ = onms.detect_image(conf[b], boxes[b], K=1024, conf_threshold=0.01, iou_threshold=0.45, max_det=200)
             assert cnt[b] == len(r) and (keep[b, :len(r)] == r).all(), f"image {b}: kept indices differ"
-        print(f"{case} inflight {nin}:", [n for n in names if any(k in n for k in ("rdirect", "stream3", "true>", "stem", "bneck"))])
+        print(f"{case} inflight {nin}:", [n for n in names if any(k in n for k in ("rdirect", "stream3", "true, false>", "false, true>", "stem", "bneck"))])
         del od
         torch.cuda.empty_cache()
