@@ -23,7 +23,9 @@ def _main():
     else:
         X_val, y_val = tk.data.voc.load_07_test(args.vocdevkit_dir)
     X_val, y_val = X_val[:1], y_val[:1]
-    od = _common.make_detector(tk, args, 1, (512, 512), use_multi_gpu=False)
+    # as the reference does (check_assign.py:19,21): the detector at ITS default input size, the generator at 512 x 512 --
+    # prior boxes live in normalised image coordinates, so encode_truth / decode_locs do not depend on the image size
+    od = _common.make_detector(tk, args, 1, use_multi_gpu=False)
     gen = tk.dl.od.od_gen.create_generator((512, 512), preprocess_input=lambda x: x, encode_truth=od.pb.encode_truth)
     g, _ = gen.flow(X_val, y_val, data_augmentation=True)
     for i, (X_batch, y_batch) in zip(tk.tqdm(range(args.batches)), g):

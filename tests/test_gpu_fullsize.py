@@ -183,10 +183,11 @@ def test_inference_at_baseline_config(cuda, B, S):
     xt = torch.from_numpy(x).to(cuda)
     od = ObjectDetector.synthetic(B, (S, S), seed=2, device=cuda, use_multi_gpu=False)
     assert od.n_inflight == 3, "bench.py's default"
+    from conftest import oracle_logits  # (od.params are W.random_init(2) = onet.init_weights(2): asserted in test_host_logic)
     t0 = time.perf_counter()
-    ref = onet.Runner(od.params, storage="f16").forward(x)
+    ref = oracle_logits(B, S, "f16")
     t_oracle = time.perf_counter() - t0
-    ref32 = onet.Runner(od.params, storage="f32").forward(x)
+    ref32 = oracle_logits(B, S, "f32")
     tickets = [od.submit(xt, conf_threshold=0.01) for _ in range(3)]  # the step bench.py times, once per pipeline
     outs = []
     for t in tickets:

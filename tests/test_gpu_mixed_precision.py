@@ -119,8 +119,9 @@ def test_mixed_plan_at_baseline_config(cuda, B, S):
     for inflight in (3, 1):
         od = ObjectDetector.synthetic(B, (S, S), seed=2, device=cuda, use_multi_gpu=False, precision="mixed", n_inflight=inflight)
         if ref32 is None:
-            ref32 = onet.Runner(od.params, storage="f32").forward(x)
-            refm = onet.MixedPlan(od.net.stream_stages, od.net.split, od.net.wide_fpn).runner(od.params).forward(x)
+            from conftest import oracle_logits
+            ref32 = oracle_logits(B, S, "f32")
+            refm = oracle_logits(B, S, ("mixed", tuple(od.net.stream_stages), tuple(od.net.split), od.net.wide_fpn))
         if inflight > 1:
             tickets = [od.submit(xt, conf_threshold=0.01) for _ in range(inflight)]
             outs = []
