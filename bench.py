@@ -457,11 +457,7 @@ def main():
             print(f"  {k:40s} n={v['n']:3d} {v['ms']:8.3f} ms {v['flops'] / (v['ms'] * 1e-3) / 1e12:8.1f} TF/s",
                   file=sys.stderr)
 
-    train_block = None
-    if world > 1 and not a.no_extra:  # every rank takes part in the collectives; rank 0 prints
-        del od
-        torch.cuda.empty_cache()
-        train_block = multi_rank_train_block(params, a, rank, world, dev, backend)
+    out = None
     if rank == 0:
         total_images = world * batch * a.steps
         out = {
@@ -517,10 +513,44 @@ def main():
             del od
             torch.cuda.empty_cache()
             out["extra"] = extra_block(params, a, dev)
-        if train_block is not None:
-            out["train"] = train_block
-        print(json.dumps(out))
+    if world > 1 and not a.no_extra:
+        # N > 1: the training step's gradient all-reduce, timed on ALL ranks (every rank takes part in the collectives; rank
+        # 0 prints).  The headline above is complete at this point, and this block has never run on more than one GPU before
+        # the driver does: a watchdog makes sure the ONE line still goes out (with the error noted) if a rank fails or a
+        # collective hangs, instead of the whole multi-GPU measurement being lost with it.
+        import threading
+        limit = float(os.environ.get("OD_BENCH_TRAIN_TIMEOUT", "300"))
+        finished = threading.Event()
+
+        def bail():
+            if finished.is_set():
+                return
+            if rank == 0:
+                out["train"] = {"error": f"the multi-rank train block did not finish within {limit:.0f} s (a rank failed or a "
+                                         f"collective hung); the inference headline above is unaffected"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        timer = threading.Timer(limit, bail)
+        timer.daemon = True
+        timer.start()
+        try:
+            tb = multi_rank_train_block(params, a, rank, world, dev, backend)
+        except Exception as e:  # noqa: BLE001 -- whatever it is, the headline line must still be printed
+            tb = {"error": f"{type(e).__name__}: {e}"}
+            if rank != 0:  # the other ranks may be waiting in a collective for this one: their watchdogs end them
+                finished.set()
+                timer.cancel()
+                os._exit(0)
+        finished.set()
+        timer.cancel()
+        if rank == 0:
+            out["train"] = tb
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
+        if out is not None and isinstance(out.get("train"), dict) and "error" in out["train"]:
+            os._exit(0)  # do not wait in destroy_process_group for ranks that are gone
         torch.distributed.destroy_process_group()
 
 
