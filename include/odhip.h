@@ -383,8 +383,10 @@ int od_cast_bf16_f32(od_ctx* ctx, const void* src, float* dst, long long n, void
 int od_pack_weights_multi(od_ctx* ctx, const float* w, const od_pack_layer* layers, int nlayers, void* stream);
 
 /* first layer's weight gradient: dw f32 [32][27] += dz^T . shifted(x_u8) * in_scale (no dX: the input is the image).
- * Runs the MFMA weight-gradient kernel over an f16 x 8-channel copy of the image kept in `workspace` (16 B per pixel + the
- * per-split slabs); fixed-order slab sum, no atomics: bit-reproducible.  workspace: 16-byte aligned, caller-owned. */
+ * Streaming kernel (W a multiple of 32: the uint8 window is read in place, one 32 x 32 f32 partial slab per workgroup);
+ * other widths run the MFMA weight-gradient kernel over an f16 x 8-channel copy of the image kept in `workspace`.  Either way
+ * a fixed-order slab sum, no atomics: bit-reproducible.  workspace: 16-byte aligned, caller-owned, sized by
+ * od_conv_first_bwd_weight_workspace_bytes (which knows which of the two forms a shape takes). */
 size_t od_conv_first_bwd_weight_workspace_bytes(od_ctx* ctx, int B, int H, int W);
 int od_conv_first_bwd_weight(od_ctx* ctx, const uint8_t* x, const void* dz, float* dw, int B, int H, int W, int Cout,
                              float in_scale, void* workspace, size_t workspace_bytes, void* stream);

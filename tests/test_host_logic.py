@@ -3,6 +3,7 @@ symbol include/odhip.h declares, prior table, VOC loader/evaluator, score report
 import ctypes
 import pathlib
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -394,3 +395,69 @@ def test_decode_chunk_into_shared_memory(tmp_path):
     r = subprocess.run([sys.executable, "-c", "import sys; import object_detector_amd.imageio; print('torch' in sys.modules)"],
                        capture_output=True, text=True, cwd=str(pathlib.Path(__file__).resolve().parent.parent))
     assert r.stdout.strip() == "False", r.stdout + r.stderr
+
+
+def test_shapes_dataset_roundtrips_through_a_voc_layout(tmp_path):
+    """The generated 'shapes' task (scripts/_common.py: what closes the train -> voc_validate loop offline) written as a
+    VOCdevkit directory and read back by tk.data.voc.load_07_test: same pixels (png), same classes, boxes to the pixel."""
+    sys.path.insert(0, str(ROOT / "scripts"))
+    import _common
+    import pytoolkit as tk
+    from PIL import Image
+    X, y = _common.shapes_dataset(5, seed=3)
+    assert len(X) == 5 and all(a.num_objects >= 1 and set(a.classes) <= set(_common.SHAPE_CLASSES) for a in y)
+    X2, y2 = _common.shapes_dataset(5, seed=3)
+    assert all(np.array_equal(a, b) for a, b in zip(X, X2))  # seeded
+    _common.write_voc_layout(tmp_path, X, y)
+    Xr, yr = tk.data.voc.load_07_test(tmp_path)
+    assert len(Xr) == 5
+    for img, a, pth, b in zip(X, y, Xr, yr):
+        assert np.array_equal(np.asarray(Image.open(pth)), img)
+        assert a.classes.tolist() == b.classes.tolist()
+        h, w = img.shape[:2]
+        np.testing.assert_allclose(b.bboxes * [w, h, w, h], a.bboxes * [w, h, w, h], atol=1e-3)
+    # every rectangle is painted in its class colour: the mean colour inside a box is close to the class colour
+    for img, a in zip(X, y):
+        h, w = img.shape[:2]
+        c, bb = int(a.classes[-1]), a.bboxes[-1]  # the last one painted is never covered
+        patch = img[int(bb[1] * h) + 2:int(bb[3] * h) - 2, int(bb[0] * w) + 2:int(bb[2] * w) - 2].reshape(-1, 3).mean(0)
+        col = np.asarray(_common.SHAPE_COLOURS[_common.SHAPE_CLASSES.index(c)], np.float64)
+        assert np.abs(patch / np.linalg.norm(patch) - col / np.linalg.norm(col)).max() < 0.08
+
+
+def test_training_script_helpers():
+    """scripts/train.py: focal-loss prior initialisation of the objectness bias, the cosine schedule; trainer.lr_multiplier with
+    the docs/MODEL.md:84-90 table and with an override."""
+    sys.path.insert(0, str(ROOT / "scripts"))
+    import train as T
+    from object_detector_amd import weights as W
+    from object_detector_amd.trainer import LR_MULTIPLIERS, lr_multiplier
+    p = T.init_for_training(W.random_init(2), prior=0.01)
+    b = p["h.out.bias"].reshape(W.NUM_PRIORS, 26)
+    obj = 1.0 / (1.0 + np.exp(b[:, 0] - b[:, 1]))
+    np.testing.assert_allclose(obj, 0.01, rtol=1e-5)
+    assert (b[:, 2:] == 0).all() and p["h.out.w"] is not None
+    f = T.cosine_schedule(0.02, 100, 10)
+    assert f(0) == pytest.approx(0.002) and f(9) == pytest.approx(0.02) and f(10) == pytest.approx(0.02)
+    assert f(99) < 1e-4 and all(f(i) >= f(i + 1) for i in range(10, 99))
+    assert LR_MULTIPLIERS == {"b.": 0.01, "h.": 1.0 / 3.0}
+    assert lr_multiplier("b.s3.0.a") == 0.01 and lr_multiplier("n.lat5") == 1.0
+    assert lr_multiplier("b.s3.0.a", {"h.": 1.0 / 3.0}) == 1.0 and lr_multiplier("h.t0", {"h.": 0.5}) == 0.5
+
+
+def test_mixed_plan_oracle_is_closer_to_fp32_than_f16_storage():
+    """oracle.network.MixedPlan (the CPU restatement of ObjectDetector(precision='mixed')) on a small input: strictly less
+    logit error than the f16-storage plan, every component of the plan contributing (the attribution DESIGN.md §5 quotes)."""
+    from oracle import network as onet
+    params = onet.init_weights(2)
+    x = onet.synthetic_images(1, 128, seed=0)
+    ref = onet.Runner(params, storage="f32").forward(x)
+    rms = lambda a: float(np.sqrt(np.mean((a - ref).astype(np.float64) ** 2)))  # noqa: E731
+    e16 = rms(onet.Runner(params, storage="f16").forward(x))
+    e_mixed = rms(onet.MixedPlan().runner(params).forward(x))
+    e_stream = rms(onet.MixedPlan((4, 5), (), True).runner(params).forward(x))
+    e_nofpn = rms(onet.MixedPlan((4, 5), ("n.lat4", "n.lat5", "n.out3", "n.out4", "h.t0", "h.out"), False).runner(params).forward(x))
+    assert e_mixed < 0.7 * e16 and e_mixed < e_stream < e16 and e_mixed < e_nofpn
+    mp = onet.MixedPlan()
+    assert mp.storage("b.s3.1.b") and not mp.storage("b.s4.1.b") and mp.storage("b.down4") and not mp.storage("n.lat5")
+    assert mp.operand_f16("b.s4.2.a") and not mp.operand_f16("h.out") and not mp.res_f16("n.lat3") and mp.res_f16("b.s3.0.b")
