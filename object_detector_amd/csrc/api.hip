@@ -5,6 +5,8 @@
 #include <string>
 #include <vector>
 
+#include <mutex>
+
 #include "common.h"
 
 static thread_local char g_err[1024] = "";
@@ -144,6 +146,10 @@ extern "C" int od_struct_fields(const char* struct_name, char* buf, int buf_byte
 }
 
 int od_ensure_lds(od_ctx* ctx, const void* fn, size_t lds) {
+  // the one piece of mutable context state: a data-generator thread (od_gen prefetch) may issue kernels beside the thread
+  // that drives the training step
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
   auto it = ctx->lds_attr.find(fn);
   if (it != ctx->lds_attr.end() && it->second >= lds) return OD_OK;
   OD_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

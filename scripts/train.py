@@ -41,6 +41,9 @@ def _main():
                         "Darknet53 is available offline)")
     p.add_argument("--seed", default=0, type=int)
     p.add_argument("--log-every", default=50, type=int)
+    p.add_argument("--no-device-cache", action="store_true",
+                   help="decode and upload every image every epoch instead of keeping the decoded dataset in HBM")
+    p.add_argument("--prefetch", default=2, type=int, help="batches the generator thread runs ahead (0 = in the training thread)")
     args = p.parse_args()
     with tk.dl.session():
         tk.log.init(args.result_dir / "train.log")
@@ -97,8 +100,9 @@ def _run(args):
     tr = Trainer(params, args.batch_size, tuple(args.input_size), device=dev, lr=args.lr, momentum=args.momentum,
                  weight_decay=args.weight_decay, comm=comm, world_size=world, lr_multipliers=mult)
     gen = od_gen.create_generator(tuple(args.input_size), preprocess_input=None, encode_truth=tr.pb.encode_truth_device,
-                                  device=dev, on_device=True)
-    batches, per_epoch = gen.flow(X, y, batch_size=args.batch_size, data_augmentation=True, shuffle=True, seed=args.seed + rank)
+                                  device=dev, on_device=True, device_cache=not args.no_device_cache)
+    batches, per_epoch = gen.flow(X, y, batch_size=args.batch_size, data_augmentation=True, shuffle=True, seed=args.seed + rank,
+                                  prefetch=args.prefetch)
     log.info(f"{n} images on rank {rank} of {world}, {per_epoch} steps per epoch, {args.steps} steps, lr {args.lr}, "
              f"multipliers {mult}")
     t0 = time.perf_counter()

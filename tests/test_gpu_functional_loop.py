@@ -47,8 +47,8 @@ def trained(cuda):
     # base network at the full rate: there is no pre-trained Darknet53 offline (docs/MODEL.md:84-90 defaults are unit-tested)
     tr = Trainer(params0, B, (S, S), device=cuda, lr=0.02, momentum=0.9, weight_decay=1e-4, lr_multipliers={"h.": 1.0 / 3.0})
     gen = od_gen.create_generator((S, S), preprocess_input=None, encode_truth=tr.pb.encode_truth_device, device=cuda,
-                                  on_device=True)
-    batches, _ = gen.flow(X, y, batch_size=B, data_augmentation=True, shuffle=True, seed=0)
+                                  on_device=True, device_cache=True)  # the decoded dataset lives in HBM
+    batches, _ = gen.flow(X, y, batch_size=B, data_augmentation=True, shuffle=True, seed=0, prefetch=2)
     hist = tr.fit(batches, STEPS, lr_schedule=train_script.cosine_schedule(0.02, STEPS, 50))
     torch.cuda.synchronize()
     params = tr.export_params()

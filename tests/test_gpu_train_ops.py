@@ -162,3 +162,57 @@ def test_generator_feeds_trainer_without_leaving_the_device(cuda):
     assert all(np.isfinite(losses)) and tr.skipped_steps == 0
     with pytest.raises(ValueError):
         od_gen.create_generator((S, S), on_device=True)
+
+
+def test_generator_prefetch_thread_yields_the_same_batches(cuda):
+    """flow(..., prefetch=N): the batches come from a background thread on its own HIP stream, N ahead -- the same pixels and
+    targets in the same order as the in-thread generator, consumable by the trainer while the thread already builds the next."""
+    import torch
+    from object_detector_amd import od_gen, weights as W
+    from object_detector_amd.pb import ObjectsAnnotation
+    from object_detector_amd.trainer import Trainer
+    rng = np.random.default_rng(0)
+    S, B = 96, 2
+    X = np.array([rng.integers(0, 256, (120, 200, 3), dtype=np.uint8) for _ in range(6)], dtype=object)
+    y = np.array([ObjectsAnnotation(None, 200, 120, [i % 20], [[0.2, 0.2, 0.7, 0.8]]) for i in range(6)], dtype=object)
+    tr = Trainer(W.random_init(2), B, (S, S), device=cuda, lr=0.01, momentum=0.0, loss_scale=256.0)
+    gen = od_gen.create_generator((S, S), preprocess_input=None, encode_truth=tr.pb.encode_truth_device, device=cuda,
+                                  on_device=True)
+    plain, _ = gen.flow(X, y, batch_size=B, data_augmentation=True, shuffle=True, seed=5)
+    ahead, _ = gen.flow(X, y, batch_size=B, data_augmentation=True, shuffle=True, seed=5, prefetch=3)
+    losses = []
+    for _i, (xa, ya), (xp, yp) in zip(range(7), plain, ahead):
+        assert xp.is_cuda and yp.is_cuda
+        losses.append(float(tr.step(xp, y_target=yp)[3]))  # consumed while the thread is already three batches further
+        assert torch.equal(xa, xp) and torch.equal(ya, yp)
+    assert all(np.isfinite(losses))
+    ahead.close()  # stops the thread
+    with pytest.raises(ValueError):
+        od_gen.create_generator((S, S), device=cuda).flow(X, y, batch_size=B, prefetch=2)
+
+
+def test_generator_device_resident_image_cache(cuda):
+    """device_cache=True: every image is decoded / uploaded once and then read by od_augment_batch where it lives in HBM
+    (images of different sizes in separate allocations: one base pointer + a 64-bit offset per image).  Same batches, bit for
+    bit, as the host-packed path over two epochs; the second epoch loads nothing."""
+    import torch
+    from object_detector_amd import od_gen
+    from object_detector_amd.pb import ObjectsAnnotation, PriorBoxes
+    rng = np.random.default_rng(1)
+    S, B = 96, 3
+    sizes = [(120, 200), (96, 64), (33, 47), (200, 120), (64, 64), (150, 170)]
+    X = np.array([rng.integers(0, 256, hw + (3,), dtype=np.uint8) for hw in sizes], dtype=object)
+    y = np.array([ObjectsAnnotation(None, hw[1], hw[0], [i], [[0.2, 0.2, 0.7, 0.8]]) for i, hw in enumerate(sizes)], dtype=object)
+    pb = PriorBoxes((S, S), 20, device=cuda)
+    plain = od_gen.create_generator((S, S), encode_truth=pb.encode_truth_device, device=cuda, on_device=True)
+    cached = od_gen.create_generator((S, S), encode_truth=pb.encode_truth_device, device=cuda, on_device=True, device_cache=True)
+    loads = []
+    orig = cached._load
+    cached._load = lambda x: (loads.append(1), orig(x))[1]
+    ga, _ = plain.flow(X, y, batch_size=B, data_augmentation=True, shuffle=True, seed=9)
+    gb, _ = cached.flow(X, y, batch_size=B, data_augmentation=True, shuffle=True, seed=9)
+    for _i, (xa, ya), (xb, yb) in zip(range(4), ga, gb):  # two epochs of two batches
+        assert torch.equal(xa, xb) and torch.equal(ya, yb)
+    assert len(loads) == len(X), "every image decoded exactly once"
+    with pytest.raises(ValueError):
+        od_gen.create_generator((S, S), device_cache=True)
