@@ -17,6 +17,8 @@ def _main():
     p.add_argument("--input-size", default=(320, 320), type=int, nargs=2)
     p.add_argument("--batch-size", default=16, type=int)
     p.add_argument("--weights", default=None, type=pathlib.Path)
+    p.add_argument("--precision", default=None, choices=("f16", "mixed"),
+                   help="mixed = every logit within 1e-3 x scale of an fp32 run (ObjectDetector(precision=...)); default f16")
     p.add_argument("--synthetic", default=0, type=int, help="N synthetic images + random-init weights instead of VOC")
     args = p.parse_args()
     with tk.dl.session():
@@ -31,7 +33,7 @@ def _run(args):
     else:
         X_test, y_test = tk.data.voc.load_07_test(args.vocdevkit_dir)
     od = _common.make_detector(tk, args, args.batch_size, tuple(args.input_size), keep_aspect=False, strict_nms=False,
-                               use_multi_gpu=True)
+                               use_multi_gpu=True, precision=args.precision)
     pred_test = od.predict(X_test)
     scores = tk.data.voc.evaluate(y_test, pred_test)
     tk.log.get(__name__).info(f'mAP={scores["mAP"] * 100:.1f} mAP(VOC2007)={scores["mAP_VOC"] * 100:.1f}')

@@ -87,11 +87,12 @@ def test_wide_add_kernel(cuda):
     assert ctx.lib.od_wide_add(ctx.handle, C.byref(d), _stream_ptr()) != 0  # odd map: rejected
 
 
-@pytest.mark.parametrize("B,S", [(2, 96), (3, 160)], ids=["2-96", "3-160"])
+@pytest.mark.parametrize("B,S", [(2, 96), (3, 160), (2, (96, 224))], ids=["2-96", "3-160", "2-96x224"])
 def test_mixed_plan_small(cuda, B, S):
     from object_detector_amd.detector import ObjectDetector
-    x = onet.synthetic_images(B, S, seed=0)
-    od = ObjectDetector.synthetic(B, (S, S), seed=2, device=cuda, use_multi_gpu=False, precision="mixed", n_inflight=1)
+    hw = (S, S) if isinstance(S, int) else S
+    x = np.random.default_rng(0).integers(0, 256, size=(B,) + hw + (3,), dtype=np.uint8)
+    od = ObjectDetector.synthetic(B, hw, seed=2, device=cuda, use_multi_gpu=False, precision="mixed", n_inflight=1)
     keep, cnt = od.predict_batch_device(torch.from_numpy(x).to(cuda), conf_threshold=0.01)
     torch.cuda.synchronize()
     got = od.net.pred.cpu().numpy()
