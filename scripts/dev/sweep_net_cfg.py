@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-network tile-config sweep: time selected layers of the real plan (cold caches, real producers/consumers around
-them) under different tile_cfg overrides.  usage: sweep_net_cfg.py --layers "b.s3*a,b.s4*a" --cfgs -1,3,24,25"""
+them) under different tile_cfg overrides.  usage: sweep_net_cfg.py --layers "b.s3*a,b.s4*a" --cfgs -1,3,6,7"""
 import argparse
 import pathlib
 import sys
@@ -21,7 +21,7 @@ def match(name, pat):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", default="b.s3*a,b.s4*a,b.s5*a")
-    ap.add_argument("--cfgs", default="-1,3,24,25,26,27,28")
+    ap.add_argument("--cfgs", default="-1,3,6,7")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=320)
     ap.add_argument("--reps", type=int, default=8)
