@@ -99,6 +99,9 @@ def stream_queue_sets(device, n, candidates=6, seed_streams=(), beside=None):
            None if beside is None else beside.cuda_stream)
     if key in _QUEUE_SETS:
         return _QUEUE_SETS[key]
+    if not hasattr(torch.cuda, "_sleep"):  # no spin kernel to probe with: creation order (what rounds 1-2 started from)
+        _QUEUE_SETS[key] = list(seed_streams)[:n] + [torch.cuda.Stream(device=device) for _ in range(n - min(n, len(seed_streams)))]
+        return _QUEUE_SETS[key]
     with torch.cuda.device(device):
         cands = list(seed_streams) + [torch.cuda.Stream(device=device) for _ in range(max(candidates, n) - len(seed_streams))]
         for c in cands:  # every stream's first launch (queue creation) happens outside the probes
