@@ -1,5 +1,7 @@
 """GPU parity of one whole training step (forward in BN-training mode, assignment, loss, backward, SGD) against the
 torch-CPU float64 oracle with the same seeded parameters, images and ground truth."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -224,3 +226,47 @@ def test_bf16_casts_round_to_nearest_even(cuda):
     _lib.check(ctx.lib.od_cast_bf16_f32(ctx.handle, dst.data_ptr(), back.data_ptr(), v.size, _stream_ptr()))
     ok = ~torch.isnan(back)
     assert torch.equal(back[ok], want.float()[ok])
+
+
+def test_bench_multi_rank_train_block_on_a_one_rank_rccl_group(cuda, tmp_path):
+    """bench.py's `train` block (what `--gpus N` appends for N > 1: training step with f32 / bf16 payload, bucketed / single
+    collective, od_allreduce alone) through the REAL RCCL path -- backend nccl, od_comm_init / od_comm_count / od_allreduce /
+    od_comm_destroy -- with the only topology one GPU offers: a 1-rank group, in a child process (it owns a process group)."""
+    import subprocess
+    import sys
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parent.parent
+    code = (
+        "import os, sys, json, argparse, torch\n"
+        f"sys.path.insert(0, {str(root)!r})\n"
+        "import bench\n"
+        "from object_detector_amd import weights as W\n"
+        "os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')\n"
+        "dev = torch.device('cuda:0'); torch.cuda.set_device(dev)\n"
+        "torch.distributed.init_process_group('nccl', device_id=dev)\n"
+        "a = argparse.Namespace(reps=2)\n"
+        "out = bench.multi_rank_train_block(W.random_init(2), a, 0, 1, dev, 'nccl')\n"
+        "torch.cuda.synchronize(); torch.distributed.destroy_process_group()\n"
+        "print('RESULT ' + json.dumps(out))\n")
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert len(line) == 1
+    import json
+    out = json.loads(line[0][7:])
+    assert out["od_comm_count"] == 1 and "RCCL" in out["collective"]
+    for key in ("step_f32_bucketed", "step_f32_single", "step_bf16_bucketed", "step_bf16_single"):
+        assert out[key]["ms_per_step"] > 0 and out[key]["skipped_steps"] == 0, key
+    assert out["step_f32_bucketed"]["collectives_per_step"] >= 4 and out["step_f32_single"]["collectives_per_step"] == 1
+    for key, nbytes in (("allreduce_only_f32", 4), ("allreduce_only_bf16", 2)):
+        assert out[key]["bytes"] % nbytes == 0 and out[key]["ms"] > 0
+    print({k: (v.get("ms_per_step") or v.get("ms")) for k, v in out.items() if isinstance(v, dict)})
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
