@@ -244,7 +244,7 @@ int od_gather_detections(od_ctx* ctx, const float* conf, const float* boxes, con
  * od_topk_scores -> od_nms on the same pred (keys come back SORTED descending here, unused slots 0).
  *   conf: optional dense f32 [B,P,NC] output (NULL in the product path);  workspace: od_detect_workspace_bytes, zeroed once
  *   with od_detect_workspace_init (every call leaves it ready for the next);  nms_workspace: od_nms_workspace_bytes(B, K).
- *   P even, NC <= 90, K <= 1024. */
+ *   P even, NC <= 76 (the limit of od_head_postprocess, whose dense form stays available for the same pred), K <= 1024. */
 size_t od_detect_workspace_bytes(int B, int P, int NC, int K);
 int od_detect_workspace_init(od_ctx* ctx, void* workspace, size_t workspace_bytes, int B, int P, int NC, void* stream);
 int od_detect(od_ctx* ctx, const float* pred, const float* priors, int B, int P, int NC, float loc_scale, int clip,

@@ -388,8 +388,8 @@ extern "C" int od_detect(od_ctx* ctx, const float* pred, const float* priors, in
                          size_t workspace_bytes, void* nms_workspace, size_t nms_workspace_bytes, void* stream) {
   OD_REQUIRE(ctx && pred && priors && boxes && keys && counts && keep_flat && keep_count && workspace && nms_workspace,
              "od_detect: null argument");
-  OD_REQUIRE(B > 0 && B <= 65535 && P > 0 && P % 2 == 0 && NC > 0 && NC <= 90 && K > 0 && K <= 1024 && max_det > 0,
-             "od_detect: bad dims (P even, NC <= 90, K <= 1024)");
+  OD_REQUIRE(B > 0 && B <= 65535 && P > 0 && P % 2 == 0 && NC > 0 && NC <= 76 && K > 0 && K <= 1024 && max_det > 0,
+             "od_detect: bad dims (P even, NC <= 76, K <= 1024)");
   OD_REQUIRE((long long)P * NC < (1LL << 31), "od_detect: P * NC must fit 31 bits");
   OD_REQUIRE(conf_threshold >= 0.f, "od_detect: conf_threshold must be >= 0 (scores are probabilities)");
   const DetLayout l = det_layout(B, P, NC);
@@ -439,7 +439,7 @@ extern "C" int od_detect(od_ctx* ctx, const float* pred, const float* priors, in
 extern "C" int od_gather_detections_pred(od_ctx* ctx, const float* pred, const float* boxes, const int32_t* keep_flat,
                                          const int32_t* keep_count, int B, int P, int NC, int max_det, float* out, void* stream) {
   OD_REQUIRE(ctx && pred && boxes && keep_flat && keep_count && out, "od_gather_detections_pred: null argument");
-  OD_REQUIRE(B > 0 && P > 0 && NC > 0 && NC <= 90 && max_det > 0, "od_gather_detections_pred: bad dims");
+  OD_REQUIRE(B > 0 && P > 0 && NC > 0 && NC <= 76 && max_det > 0, "od_gather_detections_pred: bad dims");
   hipLaunchKernelGGL(od_gather_det_pred, dim3(B), dim3(256), (size_t)256 * (NC + 6) * 4, (hipStream_t)stream, pred, boxes,
                      keep_flat, keep_count, P, NC, max_det, out);
   OD_CHECK_LAUNCH();

@@ -126,7 +126,7 @@ extern "C" int od_gather_detections(od_ctx* ctx, const float* conf, const float*
 extern "C" int od_head_postprocess(od_ctx* ctx, const float* pred, const float* priors, float* conf, float* boxes,
                                    int B, int P, int NC, float loc_scale, int clip, void* stream) {
   OD_REQUIRE(ctx && pred && priors && conf && boxes, "od_head_postprocess: null argument");
-  OD_REQUIRE(B > 0 && P > 0 && NC > 0 && NC <= 90, "od_head_postprocess: bad dims (NC <= 90)");
+  OD_REQUIRE(B > 0 && P > 0 && NC > 0 && NC <= 76, "od_head_postprocess: bad dims (NC <= 76: 256 rows x (2 NC + 6) floats of LDS)");
   const long long rows = (long long)B * P;
   const size_t lds = (size_t)PP_ROWS * (NC + 6 + NC) * sizeof(float);
   if (int rc = od_ensure_lds(ctx, (const void*)&od_head_post, lds)) return rc;

@@ -36,7 +36,7 @@ class Postprocessor:
         self._conf = None
         self._pred = None
         self._conf_valid = False
-        self.fused = P % 2 == 0 and NC <= 90
+        self.fused = P % 2 == 0 and NC <= 76
         self.boxes = torch.empty((B, P, 4), dtype=torch.float32, device=dev)
         self.keys = torch.empty((B, K), dtype=torch.int64, device=dev)  # u64 payload
         self.counts = torch.empty((B,), dtype=torch.int32, device=dev)

@@ -199,3 +199,35 @@ def test_fused_detect_equals_the_three_call_path(cuda, mode, size, K):
         assert first_counts[1] == 0
     if mode == "all_equal":
         assert (first_counts[0] == K).all()
+
+
+@pytest.mark.parametrize("NC,K,P,B", [(1, 5, 256, 2), (3, 64, 516, 1), (76, 1000, 1024, 2), (20, 1, 4100, 3), (7, 300, 132, 4),
+                                      (20, 1024, 513, 2)], ids=str)
+def test_fused_detect_other_class_counts_and_sizes(cuda, NC, K, P, B):
+    """od_detect over class counts 1..76, K = 1..1024, prior counts that do not fill a workgroup or end in a partial one --
+    against the three-call path, bit for bit.  An ODD prior count (never produced by the detector: 8 priors per cell) is not
+    taken by the fused path (its row loads need 16-byte alignment) and runs the three calls."""
+    from object_detector_amd.postprocess import Postprocessor
+    rng = np.random.default_rng(NC * 1000 + K)
+    ctr = rng.uniform(0.1, 0.9, (P, 2)).astype(np.float32)
+    wh = rng.uniform(0.05, 0.3, (P, 2)).astype(np.float32)
+    priors = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32)
+    pp = Postprocessor(B, P, NC, priors, device=cuda, topk=K, max_det=min(50, K))
+    assert pp.fused == (P % 2 == 0)
+    pred = rng.normal(0, 2, (B, P, NC + 6)).astype(np.float32)
+    pt = torch.from_numpy(pred).to(cuda)
+    for thr in (0.0, 0.05):
+        kf0, kc0 = pp.run_unfused(pt, thr)
+        torch.cuda.synchronize()
+        ref_keys, ref_counts = _sorted_valid(pp.keys, pp.counts)
+        kf0, kc0, boxes0 = kf0.clone(), kc0.clone(), pp.boxes.clone()
+        pp.keys.zero_(), pp.counts.zero_(), pp.keep_flat.zero_(), pp.keep_count.zero_(), pp.boxes.zero_()
+        kf, kc = pp.run(pt, thr)
+        torch.cuda.synchronize()
+        got_keys, got_counts = _sorted_valid(pp.keys, pp.counts)
+        assert (got_counts == ref_counts).all() and all(np.array_equal(a, b) for a, b in zip(got_keys, ref_keys))
+        assert torch.equal(kc, kc0) and torch.equal(kf, kf0) and torch.equal(pp.boxes, boxes0)
+        conf, boxes = pp.conf.cpu().numpy(), pp.boxes.cpu().numpy()
+        for b in range(B):  # and against the CPU oracle fed the device's conf / boxes
+            r, *_ = onms.detect_image(conf[b], boxes[b], K=K, conf_threshold=thr, iou_threshold=0.45, max_det=min(50, K))
+            assert int(kc[b]) == len(r) and (kf[b, :len(r)].cpu().numpy() == r).all()
