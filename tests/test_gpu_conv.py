@@ -367,3 +367,49 @@ def test_integration_md_stub_runs_a_conv(cuda):
     ref = _ref(x.astype(np.float32), w.astype(np.float32), scale, bias, stride, "leaky", 0.1)
     got = out.cpu().numpy().astype(np.float64)
     assert (np.abs(got - ref) <= 1e-3 * max(1.0, np.abs(ref).max()) + 2.0 ** -10 * np.abs(ref)).all()
+
+
+def test_conv_grouped_random_shapes(cuda):
+    """40 random grouped launches (2-3 maps of unrelated sizes down to 1 x 1, any batch, Cin a multiple of 64, ragged Cout,
+    every tile height of the 8-wave kernel, f16 / f32 output): every segment bit-identical to its own ordinary launch on
+    the same kernel, and nothing written outside the outputs (guard bands)."""
+    from object_detector_amd import _lib, ops
+    from object_detector_amd.net import Context, _stream_ptr, pack_conv_weight, pad_vec
+    import ctypes as C
+    rng = np.random.default_rng(123)
+    ctx = Context.get(cuda)
+    for it in range(40):
+        B = int(rng.integers(1, 7))
+        nseg = int(rng.integers(2, 4))
+        dims = [(int(rng.integers(1, 41)), int(rng.integers(1, 41))) for _ in range(nseg)]
+        Cin = int(rng.choice([64, 128, 192, 256]))
+        Cout = int(rng.integers(1, 41)) * 8
+        cfg = NE8 + int(rng.integers(0, NE8N))
+        out_f32 = bool(rng.integers(0, 2))
+        act = [None, "leaky", "elu"][int(rng.integers(0, 3))]
+        alpha = 0.1 if act == "leaky" else 1.0
+        w = (rng.normal(0, 1, (Cout, 3, 3, Cin)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float16).astype(np.float32)
+        scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+        bias = rng.normal(0, 0.1, Cout).astype(np.float32)
+        xs = [torch.from_numpy(rng.normal(0, 1, (B, h, wd, Cin)).astype(np.float16)).to(cuda) for h, wd in dims]
+        wp = torch.from_numpy(pack_conv_weight(w)).to(cuda)
+        sc = torch.from_numpy(pad_vec(scale, wp.shape[0])).to(cuda)
+        bi = torch.from_numpy(pad_vec(bias, wp.shape[0])).to(cuda)
+        dt = torch.float32 if out_f32 else torch.float16
+        GUARD = 256
+        bufs = [torch.full((B * h * wd * Cout + 2 * GUARD,), 777.0, dtype=dt, device=cuda) for h, wd in dims]
+        d = _lib.ConvDesc()
+        d.w, d.scale, d.bias = wp.data_ptr(), sc.data_ptr(), bi.data_ptr()
+        d.B, d.Cin, d.Cout, d.ksize, d.stride = B, Cin, Cout, 3, 1
+        d.act, d.alpha = _lib.ACT_ENUM[act], alpha
+        d.out_dtype = _lib.OD_DT_F32 if out_f32 else _lib.OD_DT_F16
+        d.tile_cfg, d.nseg = cfg, nseg
+        for i, (x, (h, wd), bf) in enumerate(zip(xs, dims, bufs)):
+            d.seg_x[i], d.seg_out[i], d.seg_H[i], d.seg_W[i] = x.data_ptr(), bf.data_ptr() + GUARD * bf.element_size(), h, wd
+        _lib.check(ctx.lib.od_conv2d_fwd(ctx.handle, C.byref(d), _stream_ptr()), "grouped")
+        torch.cuda.synchronize()
+        for x, (h, wd), bf in zip(xs, dims, bufs):
+            assert (bf[:GUARD] == 777.0).all() and (bf[-GUARD:] == 777.0).all(), (it, "guard band overwritten")
+            got = bf[GUARD:-GUARD].view(B, h, wd, Cout)
+            single = ops.conv2d(x, w, scale, bias, act=act, alpha=alpha, out_f32=out_f32, tile_cfg=cfg)
+            assert torch.equal(single, got), (it, B, dims, Cin, Cout, cfg, out_f32)
