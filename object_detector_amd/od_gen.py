@@ -319,8 +319,14 @@ def _prefetched(iterator, depth, device):
                     if isinstance(v, torch.Tensor) and v.is_cuda:
                         v.record_stream(cur)
                 yield item
-        finally:
+        finally:  # consumer closed / garbage-collected the iterator: stop the thread BEFORE the interpreter can tear down
             stop.set()
+            try:
+                while True:
+                    q.get_nowait()
+            except queue.Empty:
+                pass
+            t.join(timeout=10.0)
     return gen()
 
 

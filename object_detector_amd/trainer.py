@@ -178,6 +178,8 @@ class Trainer:
                             else None)
         self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
         self._flag_queue, self._flag_pool = [], []  # (event, pinned host flag) of steps whose flag copy is still in flight
+        self._consecutive_skips = 0
+        self.max_consecutive_skips = 50  # fit() gives up after this many skipped steps in a row (see diverged())
         self._buckets = self._make_buckets(int(self.bucket_mb * (1 << 20) / 4)) if self.cstream is not None else []
         self._next_bucket = 0
         mxc = max(self.lib.od_bn_workspace_bytes(self.B * (n.H // n.stride) * (n.W // n.stride), n.Cout) + 2 * n.Cout * 4
@@ -600,6 +602,7 @@ class Trainer:
             self._flag_queue.pop(0)
             bad = int(host[0]) != 0
             self._flag_pool.append(host)
+            self._consecutive_skips = self._consecutive_skips + 1 if bad else 0
             if bad:
                 self.skipped_steps += 1
                 self._good_steps = 0
@@ -609,6 +612,12 @@ class Trainer:
                 self._good_steps += 1
                 if self.dynamic_loss_scale and self._good_steps >= self.loss_scale_growth_interval:
                     self.loss_scale, self._good_steps = min(self.loss_scale * 2.0, 65536.0), 0
+
+    def diverged(self):
+        """True when the last `max_consecutive_skips` steps were ALL skipped although the loss scale has already been halved
+        as far as it can help: the FORWARD pass overflows f16 (the weights themselves are in a bad place -- typically a
+        learning rate too high for the batch size), which no loss scale can cure and a skipped step never changes."""
+        return self._consecutive_skips >= self.max_consecutive_skips
 
     def sgd_per_tensor(self):
         """Per-tensor form of sgd() (kept for the equality test of the multi-tensor kernels).  UNGUARDED: no non-finite
@@ -649,6 +658,11 @@ class Trainer:
             else:
                 self.step(xb, annotations=yb)
             hist[i].copy_(self.losses)
+            if self.diverged():
+                raise RuntimeError(
+                    f"training diverged: {self._consecutive_skips} consecutive steps produced non-finite values (step {i + 1}, loss "
+                    f"scale {self.loss_scale:g}); the forward pass itself overflows f16 -- lower the learning rate (it scales "
+                    f"with the batch size) or lengthen the warm-up; the weights of the last good step are intact")
             if log_every and (i + 1) % log_every == 0:
                 l = hist[i].cpu().numpy()
                 log(f"step {i + 1}/{steps} lr {self.lr:.4g} loss {l[3]:.4f} (obj {l[0]:.4f} cls {l[1]:.4f} box {l[2]:.4f}) "

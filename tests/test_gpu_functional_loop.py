@@ -203,3 +203,30 @@ def test_skipped_step_restores_running_statistics(cuda):
     torch.cuda.synchronize()
     assert tr.skipped_steps == 1 and int(tr.nonfinite.item()) == 0
     assert bool(torch.isfinite(tr.run_stats).all()) and not torch.equal(tr.run_stats, run0)
+
+
+def test_fit_reports_divergence_instead_of_skipping_forever(cuda):
+    """A forward pass that overflows f16 (weights in a bad place: what a learning rate too high for the batch size does, measured
+    at 16 x 640^2 with a 50-step warm-up) can be cured by no loss scale, and a skipped step never changes the weights: fit() used
+    to burn the remaining steps on NaN.  Now it raises after `max_consecutive_skips` skipped steps in a row; the weights of the
+    last good step are intact."""
+    from object_detector_amd.trainer import Trainer
+    from test_gpu_trainer import _setup
+    Bs, Ss = 2, 96
+    params, x, anns = _setup(cuda, Bs, Ss)
+    tr = Trainer(params, Bs, (Ss, Ss), device=cuda, lr=0.01, momentum=0.9, loss_scale=256.0)
+    tr.max_consecutive_skips = 6
+    xt = torch.from_numpy(x).to(cuda)
+    y, _n, _ = tr.pb.encode_batch(anns, return_device=True)
+
+    def batches():
+        while True:
+            yield xt, y
+    hist = tr.fit(batches(), 3)
+    assert np.isfinite(hist).all() and not tr.diverged()
+    tr.view(tr.params, "b.down3", "w").fill_(3.0e4)  # every forward pass overflows from here on
+    tr._repack()
+    p0 = tr.params.clone()
+    with pytest.raises(RuntimeError, match="training diverged"):
+        tr.fit(batches(), 40)
+    assert tr.diverged() and tr.skipped_steps >= 6 and torch.equal(tr.params, p0)
