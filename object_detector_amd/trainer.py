@@ -44,7 +44,7 @@ class Trainer:
     def __init__(self, params, batch_size, input_size=(320, 320), device="cuda:0", lr=1e-3, momentum=0.9,
                  weight_decay=0.0, loss_scale=1024.0, box_mode="smooth_l1", backbone_act=("leaky", 0.1),
                  head_act=("elu", 1.0), comm=None, world_size=1, grad_payload=None, dynamic_loss_scale=True,
-                 lr_multipliers=None):
+                 lr_multipliers=None, prior_wh=None):
         self.ctx = Context.get(device)
         self.lib = self.ctx.lib
         self.device = torch.device(device)
@@ -69,7 +69,10 @@ class Trainer:
         self.skipped_steps = 0
         self._good_steps = 0
         self.loss_scale_growth_interval = 2000
-        self.pb = PriorBoxes((self.H0, self.W0), self.num_classes, device=self.device)
+        # prior_wh: the [3, 8, 2] table of prior sizes in grid-cell units (priors.fit: KMeans over the training boxes,
+        # docs/MODEL.md:29-31); None = the frozen default table
+        self.pb = PriorBoxes((self.H0, self.W0), self.num_classes, device=self.device,
+                             **({} if prior_wh is None else {"prior_wh": prior_wh}))
         self.P = len(self.pb)
         dev = self.device
         # od_conv_desc.tile_cfg of the forward / backward-data convolutions: -1 = fastest launch on an idle chip, -2 = least

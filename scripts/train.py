@@ -42,6 +42,9 @@ def _main():
     p.add_argument("--from-scratch", action="store_true",
                    help="base network at the full learning rate instead of docs/MODEL.md:84-90's 1/100 (no pre-trained "
                         "Darknet53 is available offline)")
+    p.add_argument("--fit-priors", action="store_true",
+                   help="prior-box sizes from KMeans over the training boxes in grid-cell units (docs/MODEL.md:29-31) instead of "
+                        "the frozen default table; they travel with the weights file")
     p.add_argument("--seed", default=0, type=int)
     p.add_argument("--log-every", default=50, type=int)
     p.add_argument("--no-device-cache", action="store_true",
@@ -90,6 +93,7 @@ def _run(args):
         X, y = _common.shapes_dataset(args.shapes, seed=args.seed)
     else:
         X, y = tk.data.voc.load_set(args.vocdevkit_dir, args.year, args.image_set)
+    y_all = y
     X, y = X[rank::world], y[rank::world]  # data-parallel: images sharded by index, no collective on the data path
     n = len(X) // args.batch_size * args.batch_size
     if n == 0:
@@ -104,8 +108,13 @@ def _run(args):
     if world > 1 and torch.distributed.get_backend() == "nccl":
         comm, _ = init_comm(Context.get(dev))
     mult = {k: v for k, v in LR_MULTIPLIERS.items() if not (args.from_scratch and k == "b.")}
+    prior_wh = None
+    if args.fit_priors:  # from ALL ranks' boxes: every rank must assign against the same priors
+        from object_detector_amd import priors as PR
+        prior_wh = PR.fit(np.concatenate([a.bboxes for a in y_all if a.num_objects]), tuple(args.input_size), seed=args.seed)
+        log.info(f"fitted prior sizes (grid-cell units), level 0: {np.round(prior_wh[0], 2).tolist()}")
     tr = Trainer(params, args.batch_size, tuple(args.input_size), device=dev, lr=args.lr, momentum=args.momentum,
-                 weight_decay=args.weight_decay, comm=comm, world_size=world, lr_multipliers=mult)
+                 weight_decay=args.weight_decay, comm=comm, world_size=world, lr_multipliers=mult, prior_wh=prior_wh)
     gen = od_gen.create_generator(tuple(args.input_size), preprocess_input=None, encode_truth=tr.pb.encode_truth_device,
                                   device=dev, on_device=True, device_cache=not args.no_device_cache)
     batches, per_epoch = gen.flow(X, y, batch_size=args.batch_size, data_augmentation=True, shuffle=True, seed=args.seed + rank,
