@@ -42,6 +42,8 @@ def _main():
     p.add_argument("--from-scratch", action="store_true",
                    help="base network at the full learning rate instead of docs/MODEL.md:84-90's 1/100 (no pre-trained "
                         "Darknet53 is available offline)")
+    p.add_argument("--box-loss", default="smooth_l1", choices=("smooth_l1", "mse"),
+                   help="bounding-box loss: smooth-L1 (north_star) or the mean squared error docs/MODEL.md:46-52 describes")
     p.add_argument("--fit-priors", action="store_true",
                    help="prior-box sizes from KMeans over the training boxes in grid-cell units (docs/MODEL.md:29-31) instead of "
                         "the frozen default table; they travel with the weights file")
@@ -114,7 +116,7 @@ def _run(args):
         prior_wh = PR.fit(np.concatenate([a.bboxes for a in y_all if a.num_objects]), tuple(args.input_size), seed=args.seed)
         log.info(f"fitted prior sizes (grid-cell units), level 0: {np.round(prior_wh[0], 2).tolist()}")
     tr = Trainer(params, args.batch_size, tuple(args.input_size), device=dev, lr=args.lr, momentum=args.momentum,
-                 weight_decay=args.weight_decay, comm=comm, world_size=world, lr_multipliers=mult, prior_wh=prior_wh)
+                 weight_decay=args.weight_decay, comm=comm, world_size=world, lr_multipliers=mult, prior_wh=prior_wh, box_mode=args.box_loss)
     gen = od_gen.create_generator(tuple(args.input_size), preprocess_input=None, encode_truth=tr.pb.encode_truth_device,
                                   device=dev, on_device=True, device_cache=not args.no_device_cache)
     batches, per_epoch = gen.flow(X, y, batch_size=args.batch_size, data_augmentation=True, shuffle=True, seed=args.seed + rank,
