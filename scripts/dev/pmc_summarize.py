@@ -28,7 +28,7 @@ def main():
             if not match and "od_" not in k:
                 continue
             v = dur[k]
-            line = f"{d.rstrip('/').split('/')[-1]:14s} {k[:48]:48s} n={len(v):3d} {sum(v) / len(v):9.1f} us"
+            line = f"{d.rstrip('/').split('/')[-1]:14s} {k[:100]:100s} n={len(v):3d} {sum(v) / len(v):9.1f} us"
             for c, vals in sorted(ctr.get(k, {}).items()):
                 line += f" | {c}={sum(vals) / len(vals):.4g}"
             print(line)
